@@ -1,0 +1,212 @@
+/*
+ * hironaka_hip.h -- C ABI of the MI355X-native batched Hironaka-game environment.
+ *
+ * This is the drop-in boundary for the one hot path of honglu2875/hironaka: the
+ * vectorised state transition  shift -> [reposition] -> Newton polytope -> [rescale]
+ * -> done / reward  over point tensors laid out [batch, max_points, dim].
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes, never allocates,
+ * never synchronises, never throws, and returns an `int` status (0 = ok, < 0 = error).
+ * All data pointers are DEVICE pointers (hipMalloc'd / torch-ROCm `tensor.data_ptr()`);
+ * `stream` is a `hipStream_t` passed as `void*` (NULL = the null stream).  Calls are
+ * re-entrant per stream and capturable into a hipGraph.
+ *
+ * What each entry point replaces in the reference (paths relative to the reference root):
+ *
+ *   hk_step                  hironaka/jax/util.py:83-125      get_take_actions/take_actions
+ *                            (+ util.py:34-35 get_dones, util.py:129-149 get_reward_fn,
+ *                             recurrent_fn.py:84-121 order of operations around the step)
+ *                            hironaka/trainer/fused_game.py:150-163  (torch caller)
+ *                            hironaka/agent.py:69-72                  (list caller)
+ *   hk_shift                 hironaka/src/_jax_ops.py:76-90   shift_jax
+ *                            hironaka/src/_torch_ops.py:46-110 shift_torch
+ *                            hironaka/src/_list_ops.py:76-101  shift_lst
+ *   hk_reposition            _jax_ops.py:114-123 / _torch_ops.py:113-133 / _list_ops.py:104-133
+ *   hk_get_newton_polytope   _jax_ops.py:32-73 (remove_repeated + get_interior)
+ *                            _torch_ops.py:8-43 + _fn.py:192-213 / _list_ops.py:9-45
+ *                            (native precedent: hironaka/cpp/cppUtil.cpp:58-61
+ *                             getNewtonPolytope_approx, loaded by src/_np_ops.py:6-15)
+ *   hk_rescale               _jax_ops.py:93-111 / _torch_ops.py:136-146 / _fn.py:133-153
+ *   hk_get_dones             jax/util.py:34-35, core/tensor_points.py:118-120
+ *   hk_get_num_points        core/tensor_points.py:65-70
+ *   hk_generate_points       jax/util.py:385-392 generate_pts, trainer/trainer.py:592-600
+ *   hk_rollout               jax/jax_trainer.py:502-555 compute_rho inner loop with
+ *                            jax/players.py:28-39,142-212 fixed policies fused in
+ *   hk_zeillinger            jax/players.py:55-109 zeillinger_fn, host.py:54-95 Zeillinger
+ *   hk_get_features          jax/util.py:172-214 get_feature_fn (order_and_rescale)
+ *   hk_decode_host_class     jax/host_action_preprocess.py:8-65, src/_fn.py:241-325
+ */
+#ifndef HIRONAKA_HIP_H
+#define HIRONAKA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HK_ABI_VERSION 1
+
+/* ---- status codes -------------------------------------------------------------------- */
+#define HK_OK 0
+#define HK_ERR_NULL (-1)        /* a required pointer is NULL                              */
+#define HK_ERR_SHAPE (-2)       /* batch/max_points/dim/stride out of range                */
+#define HK_ERR_UNSUPPORTED (-3) /* dtype / kind / flag combination not implemented        */
+#define HK_ERR_ALIGN (-4)       /* pointer not aligned to its element size                 */
+#define HK_ERR_LAUNCH (-5)      /* hipLaunchKernel reported an error                       */
+#define HK_ERR_NO_DEVICE (-6)   /* no HIP device / wrong architecture                      */
+
+/* ---- scalar dtypes --------------------------------------------------------------------- */
+#define HK_F32 0
+#define HK_F64 1
+#define HK_I32 2
+#define HK_I64 3
+#define HK_U8 4
+
+/* ---- how the host's coordinate subset is handed over ---------------------------------- */
+/* a [batch, dim] multi-binary mask of dtype HK_F32/HK_F64/HK_I32/HK_I64/HK_U8 uses the
+ * dtype code itself as `coords_kind`; the remaining kinds are:                            */
+#define HK_COORDS_CLASS_I32 16 /* [batch] compressed class id (host_action_preprocess.py)  */
+#define HK_COORDS_CLASS_I64 17
+#define HK_COORDS_IN_RECORD 18 /* mask is the `dim` elements after the points in the input
+                                  record (agent observation, jax/util.py:66-74)            */
+#define HK_COORDS_NONE 19      /* no shift stage                                           */
+
+/* ---- pipeline stages (bitmask) --------------------------------------------------------- */
+#define HK_STAGE_SHIFT 1u
+#define HK_STAGE_REPOSITION 2u
+#define HK_STAGE_NEWTON 4u
+#define HK_STAGE_RESCALE 8u
+
+/* ---- semantics: which sibling implementation of the reference is reproduced ----------- */
+#define HK_SEM_JAX 0u   /* hironaka/src/_jax_ops.py   (the path the JAX trainer runs)       */
+#define HK_SEM_TORCH 1u /* hironaka/src/_torch_ops.py (TensorPoints / FusedGame)           */
+#define HK_SEM_LIST 2u  /* hironaka/src/_list_ops.py  (ListPoints / gym envs)              */
+#define HK_SEM_MASK 3u
+
+/* ---- behaviour flags (OR-ed with the semantics code) ---------------------------------- */
+#define HK_FLAG_AXIS_NOOP_IF_INVALID 4u /* axis not in subset => no shift (torch/list)     */
+#define HK_FLAG_IGNORE_ENDED 8u         /* games with < 2 points are not shifted (torch)   */
+#define HK_FLAG_COMPACT_SORTED 16u      /* Newton output sorted descending-lex + compacted
+                                           (list semantics, _list_ops.py:25-41)            */
+#define HK_FLAG_FORCE_GENERIC 32u       /* testing: bypass the specialised kernels          */
+
+/* ---- fixed policies fused into hk_rollout (jax/players.py) ----------------------------- */
+#define HK_HOST_RANDOM 0    /* players.py:28-39   uniform class id                          */
+#define HK_HOST_ALL_COORD 1 /* players.py:42-52   all coordinates                          */
+#define HK_HOST_ZEILLINGER 2 /* players.py:84-109                                           */
+#define HK_AGENT_RANDOM 0       /* players.py:142-153 uniform over all `dim` axes (JAX)    */
+#define HK_AGENT_RANDOM_LEGAL 1 /* trainer/player_modules/modules.py:48-52, agent.py:85-90 */
+#define HK_AGENT_CHOOSE_FIRST 2 /* players.py:156-183                                      */
+#define HK_AGENT_CHOOSE_LAST 3  /* players.py:186-212                                      */
+
+/* One fused state transition over a batch of games.  A *record* is one game's row of the
+ * input/output matrices: `max_points*dim` point coordinates, optionally followed by other
+ * columns (the agent observation carries the `dim` coordinate mask there).               */
+typedef struct hk_step_desc {
+  const void* points_in; /* [batch, in_stride]                                            */
+  void* points_out;      /* [batch, out_stride]; may equal points_in if strides are equal */
+  int64_t in_stride;     /* elements between consecutive games, >= max_points*dim          */
+  int64_t out_stride;    /* only the first max_points*dim elements of a record are written */
+  const void* coords;    /* see coords_kind; ignored for IN_RECORD / NONE                  */
+  int64_t coords_stride; /* elements between games for mask kinds (>= dim)                 */
+  const void* axis;      /* [batch], dtype axis_dtype (HK_I32/I64/F32/F64); NULL w/o shift */
+  uint8_t* done_out;      /* [batch] or NULL: (#rows with x_0 >= 0) < 2 after the step     */
+  uint8_t* prev_done_out; /* [batch] or NULL: the same before the step                     */
+  void* reward_out;       /* [batch] f32 or NULL: reward_sign * (done && !prev_done)       */
+  int32_t* num_points_out; /* [batch] or NULL: #rows with x_0 >= 0 after the step          */
+  double padding_value;   /* value written into removed rows (negative; -1.0 by default)  */
+  float reward_sign;      /* +1 host, -1 agent (jax/util.py:138-144)                       */
+  int32_t batch;
+  int32_t max_points;
+  int32_t dim;
+  int32_t dtype;       /* HK_F32 or HK_F64: element type of points_in / points_out        */
+  int32_t coords_kind; /* dtype code of a mask, or HK_COORDS_*                             */
+  int32_t axis_dtype;
+  uint32_t stages; /* HK_STAGE_* bitmask, applied in the order shift, reposition, newton,
+                      rescale                                                              */
+  uint32_t flags;  /* HK_SEM_* | HK_FLAG_*                                                  */
+} hk_step_desc;
+
+/* T fused steps with the host and agent policies evaluated inside the kernel; the state
+ * never leaves the chip between steps.  Randomness is Philox4x32-10 keyed by `seed`, with
+ * counter (global game index, step index, stream id) -- defined in DESIGN.md so that the
+ * CPU oracle reproduces every action bit for bit and a sharded run equals the unsharded
+ * one.                                                                                    */
+typedef struct hk_rollout_desc {
+  void* points;           /* [batch, max_points*dim] state, updated in place              */
+  uint64_t* done_count;   /* [steps+1] or NULL; += #finished games before step 0 and after
+                             each step (caller zeroes; accumulates across shards)          */
+  void* obs_out;          /* [steps, batch, max_points*dim] or NULL: state before each step */
+  int32_t* host_class_out; /* [steps, batch] or NULL: class id chosen by the host          */
+  int32_t* axis_out;       /* [steps, batch] or NULL: axis chosen by the agent             */
+  uint8_t* done_out;       /* [steps, batch] or NULL: done after each step                 */
+  float* reward_out;       /* [steps, batch] or NULL                                       */
+  int32_t* game_length_out; /* [batch] or NULL: number of steps after which the game was
+                               first done (0 = done at entry, -1 = not within this call)   */
+  uint64_t seed;
+  uint64_t game_offset; /* global index of this shard's first game                         */
+  uint32_t step_offset; /* global index of the first step of this call                     */
+  double padding_value;
+  float reward_sign;
+  int32_t batch;
+  int32_t max_points;
+  int32_t dim;
+  int32_t dtype;
+  int32_t steps;
+  int32_t host_policy;
+  int32_t agent_policy;
+  uint32_t stages;
+  uint32_t flags;
+} hk_rollout_desc;
+
+/* ---- library ---------------------------------------------------------------------------- */
+int hk_abi_version(void);
+const char* hk_strerror(int status);
+/* 1 if (max_points, dim, dtype) has a register-resident specialised kernel, else 0.       */
+int hk_has_fast_path(int max_points, int dim, int dtype);
+
+/* ---- the fused step --------------------------------------------------------------------- */
+int hk_step(const hk_step_desc* desc, void* stream);
+
+/* ---- the reference's individual operators (thin wrappers over the same kernel) -------- */
+int hk_shift(const void* points_in, void* points_out, const void* coords, int coords_kind,
+             const void* axis, int axis_dtype, int batch, int max_points, int dim, int dtype,
+             double padding_value, uint32_t flags, void* stream);
+int hk_reposition(const void* points_in, void* points_out, int batch, int max_points, int dim,
+                  int dtype, double padding_value, uint32_t flags, void* stream);
+int hk_get_newton_polytope(const void* points_in, void* points_out, int batch, int max_points,
+                           int dim, int dtype, double padding_value, uint32_t flags,
+                           void* stream);
+int hk_rescale(const void* points_in, void* points_out, int batch, int max_points, int dim,
+               int dtype, double padding_value, uint32_t flags, void* stream);
+int hk_get_dones(const void* points, int64_t stride, uint8_t* done_out, int batch,
+                 int max_points, int dim, int dtype, void* stream);
+int hk_get_num_points(const void* points, int64_t stride, int32_t* num_points_out, int batch,
+                      int max_points, int dim, int dtype, void* stream);
+
+/* ---- state generation: randint[0, max_value) -> stages (newton / reposition / rescale) -- */
+int hk_generate_points(void* points_out, int batch, int max_points, int dim, int dtype,
+                       int max_value, uint64_t seed, uint64_t game_offset, uint32_t stages,
+                       double padding_value, uint32_t flags, void* stream);
+
+/* ---- fused T-step rollout with in-kernel fixed policies -------------------------------- */
+int hk_rollout(const hk_rollout_desc* desc, void* stream);
+
+/* ---- fixed host policy as its own operator: class id per game -------------------------- */
+int hk_zeillinger(const void* points, int64_t stride, int32_t* class_out, int batch,
+                  int max_points, int dim, int dtype, void* stream);
+
+/* ---- observation transform: [rescale] + rows sorted descending, last coordinate primary */
+int hk_get_features(const void* points_in, int64_t in_stride, void* features_out,
+                    int64_t out_stride, int batch, int max_points, int dim, int dtype,
+                    int scale_observation, double padding_value, void* stream);
+
+/* ---- host action codec ------------------------------------------------------------------ */
+int hk_decode_host_class(const int32_t* class_in, void* mask_out, int mask_dtype, int batch,
+                         int dim, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIRONAKA_HIP_H */
