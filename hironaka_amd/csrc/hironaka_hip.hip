@@ -1,0 +1,354 @@
+// C ABI of libhironaka_hip.so (include/hironaka_hip.h): argument validation, kernel selection
+// and launch.  No allocation, no synchronisation, no exceptions; every entry point returns a
+// status code.  gfx950 only.
+#include "hk_fast_kernel.h"
+#include "hk_generic_kernel.h"
+
+using namespace hk;
+
+namespace {
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+inline size_t elem_size(int dtype) { return dtype == HK_F64 ? 8 : 4; }
+
+int check_spec(int batch, int m, int d, int dtype) {
+  if (batch < 0 || m < 1 || d < 1 || d > kMaxDim) return HK_ERR_SHAPE;
+  if ((int64_t)m * d > (1 << 20)) return HK_ERR_SHAPE;
+  if (dtype != HK_F32 && dtype != HK_F64) return HK_ERR_UNSUPPORTED;
+  return HK_OK;
+}
+
+// LDS geometry of the generic kernel: odd per-game stride, as many games per wave as fit
+int plan_generic(Params& prm, int dtype) {
+  const int n = prm.m * prm.d;
+  int stride = n + prm.d;
+  stride |= 1;
+  const int64_t per_game = (int64_t)stride * (int64_t)elem_size(dtype);
+  int gpb = kWave;
+  while (gpb > 1 && per_game * gpb > kMaxLdsBytes) gpb >>= 1;
+  if (per_game * gpb > kMaxLdsBytes) return HK_ERR_UNSUPPORTED;
+  prm.lds_stride = stride;
+  prm.games_per_block = gpb;
+  return HK_OK;
+}
+
+template <typename T>
+int launch_generic_t(const Params& prm, hipStream_t stream) {
+  const size_t lds = (size_t)prm.lds_stride * prm.games_per_block * sizeof(T);
+  if (lds > 64 * 1024) {
+    // opting in to > 64 KiB of dynamic LDS is a per-function attribute (idempotent, cheap)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_kernel<T>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return HK_ERR_LAUNCH;
+    }
+  }
+  const unsigned grid = (unsigned)(((int64_t)prm.batch + prm.games_per_block - 1) / prm.games_per_block);
+  hipLaunchKernelGGL(generic_kernel<T>, dim3(grid), dim3(kWave), lds, stream, prm);
+  return hipGetLastError() == hipSuccess ? HK_OK : HK_ERR_LAUNCH;
+}
+
+int launch_generic(Params& prm, int dtype, hipStream_t stream) {
+  if (prm.batch == 0) return HK_OK;
+  const int st = plan_generic(prm, dtype);
+  if (st != HK_OK) return st;
+  return dtype == HK_F32 ? launch_generic_t<float>(prm, stream) : launch_generic_t<double>(prm, stream);
+}
+
+int launch(Params& prm, int dtype, hipStream_t stream) {
+  if (prm.batch == 0) return HK_OK;
+  if (!(prm.flags & HK_FLAG_FORCE_GENERIC)) {
+    const int st = launch_fast(prm, dtype, stream);
+    if (st != HK_ERR_UNSUPPORTED) return st;
+  }
+  return launch_generic(prm, dtype, stream);
+}
+
+int valid_coords_kind(int kind) {
+  return (kind >= HK_F32 && kind <= HK_U8) || kind == HK_COORDS_CLASS_I32 ||
+         kind == HK_COORDS_CLASS_I64 || kind == HK_COORDS_IN_RECORD;
+}
+
+size_t coords_align(int kind) {
+  switch (kind) {
+    case HK_F64: case HK_I64: case HK_COORDS_CLASS_I64: return 8;
+    case HK_U8: return 1;
+    default: return 4;
+  }
+}
+
+int params_from_step(const hk_step_desc* s, Params& prm) {
+  if (!s) return HK_ERR_NULL;
+  int st = check_spec(s->batch, s->max_points, s->dim, s->dtype);
+  if (st != HK_OK) return st;
+  if (s->batch == 0) { prm.batch = 0; return HK_OK; }
+  if (!s->points_in || !s->points_out) return HK_ERR_NULL;
+  const int64_t n = (int64_t)s->max_points * s->dim;
+  if (s->in_stride < n || s->out_stride < n) return HK_ERR_SHAPE;
+  const size_t es = elem_size(s->dtype);
+  if (!aligned(s->points_in, es) || !aligned(s->points_out, es)) return HK_ERR_ALIGN;
+  if (s->stages & ~(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON | HK_STAGE_RESCALE | kStageFeatureSort))
+    return HK_ERR_UNSUPPORTED;
+  if ((s->flags & HK_SEM_MASK) == HK_SEM_MASK) return HK_ERR_UNSUPPORTED;
+  prm = Params{};
+  if (s->stages & HK_STAGE_SHIFT) {
+    if (!valid_coords_kind(s->coords_kind)) return HK_ERR_UNSUPPORTED;
+    if (!s->axis) return HK_ERR_NULL;
+    if (s->axis_dtype < HK_F32 || s->axis_dtype > HK_I64) return HK_ERR_UNSUPPORTED;
+    if (!aligned(s->axis, (s->axis_dtype == HK_F64 || s->axis_dtype == HK_I64) ? 8 : 4)) return HK_ERR_ALIGN;
+    if (s->coords_kind == HK_COORDS_IN_RECORD) {
+      if (s->in_stride < n + s->dim) return HK_ERR_SHAPE;
+    } else {
+      if (!s->coords) return HK_ERR_NULL;
+      if (!aligned(s->coords, coords_align(s->coords_kind))) return HK_ERR_ALIGN;
+      if (s->coords_kind <= HK_U8 && s->coords_stride < s->dim) return HK_ERR_SHAPE;
+    }
+    prm.coords = s->coords;
+    prm.coords_stride = s->coords_stride;
+    prm.coords_kind = s->coords_kind;
+    prm.axis = s->axis;
+    prm.axis_dtype = s->axis_dtype;
+  } else {
+    prm.coords_kind = HK_COORDS_NONE;
+  }
+  if (s->reward_out && !aligned(s->reward_out, 4)) return HK_ERR_ALIGN;
+  if (s->num_points_out && !aligned(s->num_points_out, 4)) return HK_ERR_ALIGN;
+  prm.in = s->points_in;
+  prm.out = s->points_out;
+  prm.in_stride = s->in_stride;
+  prm.out_stride = s->out_stride;
+  prm.done_out = s->done_out;
+  prm.prev_done_out = s->prev_done_out;
+  prm.reward_out = (float*)s->reward_out;
+  prm.num_points_out = s->num_points_out;
+  prm.pad = s->padding_value;
+  prm.reward_sign = s->reward_sign;
+  prm.batch = s->batch;
+  prm.m = s->max_points;
+  prm.d = s->dim;
+  prm.stages = s->stages;
+  prm.flags = s->flags;
+  prm.mode = kModeStep;
+  return HK_OK;
+}
+
+hk_step_desc plain_desc(const void* in, void* out, int batch, int m, int d, int dtype, double pad,
+                        uint32_t stages, uint32_t flags) {
+  hk_step_desc s{};
+  s.points_in = in;
+  s.points_out = out;
+  s.in_stride = s.out_stride = (int64_t)m * d;
+  s.coords_kind = HK_COORDS_NONE;
+  s.padding_value = pad;
+  s.reward_sign = 1.0f;
+  s.batch = batch;
+  s.max_points = m;
+  s.dim = d;
+  s.dtype = dtype;
+  s.stages = stages;
+  s.flags = flags;
+  return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hk_abi_version(void) { return HK_ABI_VERSION; }
+
+const char* hk_strerror(int status) {
+  switch (status) {
+    case HK_OK: return "ok";
+    case HK_ERR_NULL: return "a required pointer is NULL";
+    case HK_ERR_SHAPE: return "batch / max_points / dim / stride / class id out of range";
+    case HK_ERR_UNSUPPORTED: return "dtype, kind or flag combination not supported";
+    case HK_ERR_ALIGN: return "pointer not aligned to its element size";
+    case HK_ERR_LAUNCH: return "HIP kernel launch failed";
+    case HK_ERR_NO_DEVICE: return "no HIP device";
+  }
+  return "unknown status";
+}
+
+int hk_has_fast_path(int max_points, int dim, int dtype) { return has_fast_path(max_points, dim, dtype); }
+
+int hk_step(const hk_step_desc* desc, void* stream) {
+  Params prm{};
+  const int st = params_from_step(desc, prm);
+  if (st != HK_OK) return st;
+  return launch(prm, desc->dtype, (hipStream_t)stream);
+}
+
+int hk_shift(const void* points_in, void* points_out, const void* coords, int coords_kind,
+             const void* axis, int axis_dtype, int batch, int max_points, int dim, int dtype,
+             double padding_value, uint32_t flags, void* stream) {
+  hk_step_desc s = plain_desc(points_in, points_out, batch, max_points, dim, dtype, padding_value,
+                              HK_STAGE_SHIFT, flags);
+  s.coords = coords;
+  s.coords_kind = coords_kind;
+  s.coords_stride = dim;
+  s.axis = axis;
+  s.axis_dtype = axis_dtype;
+  return hk_step(&s, stream);
+}
+
+int hk_reposition(const void* points_in, void* points_out, int batch, int max_points, int dim,
+                  int dtype, double padding_value, uint32_t flags, void* stream) {
+  hk_step_desc s = plain_desc(points_in, points_out, batch, max_points, dim, dtype, padding_value,
+                              HK_STAGE_REPOSITION, flags);
+  return hk_step(&s, stream);
+}
+
+int hk_get_newton_polytope(const void* points_in, void* points_out, int batch, int max_points,
+                           int dim, int dtype, double padding_value, uint32_t flags, void* stream) {
+  hk_step_desc s = plain_desc(points_in, points_out, batch, max_points, dim, dtype, padding_value,
+                              HK_STAGE_NEWTON, flags);
+  return hk_step(&s, stream);
+}
+
+int hk_rescale(const void* points_in, void* points_out, int batch, int max_points, int dim,
+               int dtype, double padding_value, uint32_t flags, void* stream) {
+  hk_step_desc s = plain_desc(points_in, points_out, batch, max_points, dim, dtype, padding_value,
+                              HK_STAGE_RESCALE, flags);
+  return hk_step(&s, stream);
+}
+
+int hk_get_dones(const void* points, int64_t stride, uint8_t* done_out, int batch, int max_points,
+                 int dim, int dtype, void* stream) {
+  int st = check_spec(batch, max_points, dim, dtype);
+  if (st != HK_OK) return st;
+  if (batch == 0) return HK_OK;
+  if (!points || !done_out) return HK_ERR_NULL;
+  if (stride < (int64_t)max_points * dim) return HK_ERR_SHAPE;
+  if (!aligned(points, elem_size(dtype))) return HK_ERR_ALIGN;
+  return launch_counts(points, stride, done_out, nullptr, batch, max_points, dim, dtype, (hipStream_t)stream);
+}
+
+int hk_get_num_points(const void* points, int64_t stride, int32_t* num_points_out, int batch,
+                      int max_points, int dim, int dtype, void* stream) {
+  int st = check_spec(batch, max_points, dim, dtype);
+  if (st != HK_OK) return st;
+  if (batch == 0) return HK_OK;
+  if (!points || !num_points_out) return HK_ERR_NULL;
+  if (stride < (int64_t)max_points * dim) return HK_ERR_SHAPE;
+  if (!aligned(points, elem_size(dtype)) || !aligned(num_points_out, 4)) return HK_ERR_ALIGN;
+  return launch_counts(points, stride, nullptr, num_points_out, batch, max_points, dim, dtype, (hipStream_t)stream);
+}
+
+int hk_generate_points(void* points_out, int batch, int max_points, int dim, int dtype,
+                       int max_value, uint64_t seed, uint64_t game_offset, uint32_t stages,
+                       double padding_value, uint32_t flags, void* stream) {
+  int st = check_spec(batch, max_points, dim, dtype);
+  if (st != HK_OK) return st;
+  if (batch == 0) return HK_OK;
+  if (!points_out) return HK_ERR_NULL;
+  if (max_value < 1) return HK_ERR_SHAPE;
+  if (!aligned(points_out, elem_size(dtype))) return HK_ERR_ALIGN;
+  if (stages & ~(HK_STAGE_REPOSITION | HK_STAGE_NEWTON | HK_STAGE_RESCALE)) return HK_ERR_UNSUPPORTED;
+  if ((flags & HK_SEM_MASK) == HK_SEM_MASK) return HK_ERR_UNSUPPORTED;
+  Params prm{};
+  prm.out = points_out;
+  prm.out_stride = (int64_t)max_points * dim;
+  prm.in_stride = prm.out_stride;
+  prm.coords_kind = HK_COORDS_NONE;
+  prm.seed = seed;
+  prm.game_offset = game_offset;
+  prm.max_value = max_value;
+  prm.pad = padding_value;
+  prm.batch = batch;
+  prm.m = max_points;
+  prm.d = dim;
+  prm.stages = stages;
+  prm.flags = flags;
+  prm.mode = kModeGenerate;
+  return launch(prm, dtype, (hipStream_t)stream);
+}
+
+int hk_rollout(const hk_rollout_desc* r, void* stream) {
+  if (!r) return HK_ERR_NULL;
+  int st = check_spec(r->batch, r->max_points, r->dim, r->dtype);
+  if (st != HK_OK) return st;
+  if (r->steps < 0) return HK_ERR_SHAPE;
+  if (r->batch == 0) return HK_OK;
+  if (!r->points) return HK_ERR_NULL;
+  if (r->dim < 2) return HK_ERR_SHAPE;  // the host needs a subset of >= 2 coordinates
+  if (!aligned(r->points, elem_size(r->dtype))) return HK_ERR_ALIGN;
+  if (r->done_count && !aligned(r->done_count, 8)) return HK_ERR_ALIGN;
+  if (r->host_policy < HK_HOST_RANDOM || r->host_policy > HK_HOST_ZEILLINGER) return HK_ERR_UNSUPPORTED;
+  if (r->agent_policy < HK_AGENT_RANDOM || r->agent_policy > HK_AGENT_CHOOSE_LAST) return HK_ERR_UNSUPPORTED;
+  if (r->stages & ~(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON | HK_STAGE_RESCALE)) return HK_ERR_UNSUPPORTED;
+  if ((r->flags & HK_SEM_MASK) == HK_SEM_MASK) return HK_ERR_UNSUPPORTED;
+  Params prm{};
+  prm.in = r->points;
+  prm.out = r->points;
+  prm.in_stride = prm.out_stride = (int64_t)r->max_points * r->dim;
+  prm.coords_kind = HK_COORDS_NONE;
+  prm.done_count = (unsigned long long*)r->done_count;
+  prm.obs_out = r->obs_out;
+  prm.r_host_class_out = r->host_class_out;
+  prm.r_axis_out = r->axis_out;
+  prm.r_done_out = r->done_out;
+  prm.r_reward_out = r->reward_out;
+  prm.game_length_out = r->game_length_out;
+  prm.seed = r->seed;
+  prm.game_offset = r->game_offset;
+  prm.step_offset = r->step_offset;
+  prm.steps = r->steps;
+  prm.host_policy = r->host_policy;
+  prm.agent_policy = r->agent_policy;
+  prm.pad = r->padding_value;
+  prm.reward_sign = r->reward_sign;
+  prm.batch = r->batch;
+  prm.m = r->max_points;
+  prm.d = r->dim;
+  prm.stages = r->stages;
+  prm.flags = r->flags;
+  prm.mode = kModeRollout;
+  return launch(prm, r->dtype, (hipStream_t)stream);
+}
+
+int hk_zeillinger(const void* points, int64_t stride, int32_t* class_out, int batch,
+                  int max_points, int dim, int dtype, void* stream) {
+  int st = check_spec(batch, max_points, dim, dtype);
+  if (st != HK_OK) return st;
+  if (batch == 0) return HK_OK;
+  if (!points || !class_out) return HK_ERR_NULL;
+  if (dim < 2) return HK_ERR_SHAPE;
+  if (stride < (int64_t)max_points * dim) return HK_ERR_SHAPE;
+  if (!aligned(points, elem_size(dtype)) || !aligned(class_out, 4)) return HK_ERR_ALIGN;
+  Params prm{};
+  prm.in = points;
+  prm.in_stride = stride;
+  prm.out_stride = stride;
+  prm.class_out = class_out;
+  prm.coords_kind = HK_COORDS_NONE;
+  prm.batch = batch;
+  prm.m = max_points;
+  prm.d = dim;
+  prm.mode = kModeZeillinger;
+  return launch_generic(prm, dtype, (hipStream_t)stream);
+}
+
+int hk_get_features(const void* points_in, int64_t in_stride, void* features_out,
+                    int64_t out_stride, int batch, int max_points, int dim, int dtype,
+                    int scale_observation, double padding_value, void* stream) {
+  hk_step_desc s = plain_desc(points_in, features_out, batch, max_points, dim, dtype, padding_value,
+                              (scale_observation ? HK_STAGE_RESCALE : 0u) | kStageFeatureSort, HK_SEM_JAX);
+  s.in_stride = in_stride;
+  s.out_stride = out_stride;
+  Params prm{};
+  const int st = params_from_step(&s, prm);
+  if (st != HK_OK) return st;
+  return launch_generic(prm, dtype, (hipStream_t)stream);
+}
+
+int hk_decode_host_class(const int32_t* class_in, void* mask_out, int mask_dtype, int batch,
+                         int dim, void* stream) {
+  if (batch < 0 || dim < 2 || dim > kMaxDim) return HK_ERR_SHAPE;
+  if (batch == 0) return HK_OK;
+  if (!class_in || !mask_out) return HK_ERR_NULL;
+  if (mask_dtype < HK_F32 || mask_dtype > HK_U8) return HK_ERR_UNSUPPORTED;
+  if (!aligned(class_in, 4) || !aligned(mask_out, coords_align(mask_dtype))) return HK_ERR_ALIGN;
+  return launch_decode(class_in, mask_out, mask_dtype, batch, dim, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+// Shared device/host definitions for the HIP kernels of the batched Hironaka step.
+// gfx950 (MI355X) only: wave = 64 lanes, 160 KiB LDS per CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hironaka_hip.h"
+
+namespace hk {
+
+constexpr int kWave = 64;
+constexpr int kMaxLdsBytes = 160 * 1024;  // one workgroup may own the CU's whole LDS
+constexpr int kMaxDim = 30;               // subsets travel as 32-bit masks
+
+// internal stage bits (beyond the public HK_STAGE_*)
+constexpr unsigned kStageFeatureSort = 1u << 8;  // jax/util.py:186-197 row ordering
+
+enum Mode : int { kModeStep = 0, kModeRollout = 1, kModeGenerate = 2, kModeZeillinger = 3 };
+
+// RNG stream ids (DESIGN.md "Randomness"); the oracle uses the same two numbers.
+constexpr uint32_t kStreamPolicy = 0u;
+constexpr uint32_t kStreamGenerate = 1u;
+
+// Kernel argument block (passed by value).  Union of what the modes need.
+struct Params {
+  const void* in;
+  void* out;
+  int64_t in_stride;
+  int64_t out_stride;
+  const void* coords;
+  int64_t coords_stride;
+  const void* axis;
+  uint8_t* done_out;
+  uint8_t* prev_done_out;
+  float* reward_out;
+  int32_t* num_points_out;
+  int32_t* class_out;  // zeillinger operator
+  // rollout
+  unsigned long long* done_count;
+  void* obs_out;
+  int32_t* r_host_class_out;
+  int32_t* r_axis_out;
+  uint8_t* r_done_out;
+  float* r_reward_out;
+  int32_t* game_length_out;
+  uint64_t seed;
+  uint64_t game_offset;
+  uint32_t step_offset;
+  int32_t steps;
+  int32_t host_policy;
+  int32_t agent_policy;
+  int32_t max_value;  // generate
+  double pad;
+  float reward_sign;
+  int32_t batch;
+  int32_t m;
+  int32_t d;
+  int32_t coords_kind;
+  int32_t axis_dtype;
+  uint32_t stages;
+  uint32_t flags;
+  int32_t lds_stride;       // elements per game in LDS (generic kernel)
+  int32_t games_per_block;  // <= 64
+  int32_t mode;
+};
+
+// ---- Philox4x32-10 ------------------------------------------------------------------------
+struct U4 {
+  uint32_t x, y, z, w;
+};
+
+__host__ __device__ inline U4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                         uint64_t seed) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+
+// floor(r * n / 2^32): 32-bit word -> [0, n)
+__host__ __device__ inline uint32_t mulhi32(uint32_t r, uint32_t n) {
+  return (uint32_t)(((uint64_t)r * n) >> 32);
+}
+
+// ---- host action codec (jax/host_action_preprocess.py:8-24,78-87) -------------------------
+// class id -> bitmask (bit j <-> coordinate j): the cls-th integer >= 3 that is not a power of
+// two.  Integers with top bit L hold classes [2^L - L - 1, 2^(L+1) - L - 3].
+__host__ __device__ inline uint32_t decode_class(int cls, int d) {
+  for (int L = 1; L < d; ++L) {
+    const int hi = (int)(2u << L) - L - 3;
+    if (cls <= hi) return (uint32_t)(cls + L + 2);
+  }
+  return 3u;
+}
+
+__host__ __device__ inline int encode_mask(uint32_t v) {
+  int lg = 0;
+  while ((v >> (lg + 1)) != 0) ++lg;
+  return (int)v - lg - 2;
+}
+
+__device__ inline double load_scalar(const void* base, int dtype, size_t idx) {
+  switch (dtype) {
+    case HK_F32: return (double)((const float*)base)[idx];
+    case HK_F64: return ((const double*)base)[idx];
+    case HK_I32: return (double)((const int32_t*)base)[idx];
+    case HK_I64: return (double)((const long long*)base)[idx];
+    case HK_U8: return (double)((const uint8_t*)base)[idx];
+  }
+  return 0.0;
+}
+
+// `arange(d) == axis` (_jax_ops.py:79): non-integral / out-of-range values match nothing.
+__device__ inline int axis_index(double a, int d) {
+  if (!(a >= 0.0) || a >= (double)d || a != floor(a)) return -1;
+  return (int)a;
+}
+
+// the f32-typed padding of the torch sibling (see oracle/hko_impl.inc torch_pad)
+template <typename T>
+__device__ inline T torch_pad(T pad) {
+  return (T)(float)pad;
+}
+
+}  // namespace hk

@@ -1,0 +1,342 @@
+"""Torch-tensor front end of the HIP operators (``include/hironaka_hip.h``).
+
+Tensors are used for device memory and streams only; every function validates its arguments,
+fills a C descriptor, calls the C ABI on the current HIP stream and raises on a non-zero status.
+There is no CPU path: a non-CUDA tensor is a TypeError.
+
+Operator names follow the reference's operator layer (hironaka/src/__init__.py:22-46):
+``shift``, ``get_newton_polytope``, ``reposition``, ``rescale`` with ``sem`` selecting which
+sibling's semantics is reproduced ("jax" = _jax_ops.py, "torch" = _torch_ops.py, "list" =
+_list_ops.py on padded arrays).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import _abi as A
+from ._lib import check, lib
+
+_TORCH2HK = {torch.float32: A.HK_F32, torch.float64: A.HK_F64, torch.int32: A.HK_I32,
+             torch.int64: A.HK_I64, torch.uint8: A.HK_U8, torch.bool: A.HK_U8}
+ALL_STAGES = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON | A.HK_STAGE_RESCALE
+
+
+def make_flags(sem: str = "jax", noop_if_invalid: bool = False, ignore_ended: bool = False,
+               compact_sorted: bool = False, force_generic: bool = False) -> int:
+    if sem not in A.SEMANTICS:
+        raise ValueError(f"sem must be one of {sorted(A.SEMANTICS)}. Got {sem}.")
+    f = A.SEMANTICS[sem]
+    if noop_if_invalid:
+        f |= A.HK_FLAG_AXIS_NOOP_IF_INVALID
+    if ignore_ended:
+        f |= A.HK_FLAG_IGNORE_ENDED
+    if compact_sorted:
+        f |= A.HK_FLAG_COMPACT_SORTED
+    if force_generic:
+        f |= A.HK_FLAG_FORCE_GENERIC
+    return f
+
+
+def make_stages(shift=False, reposition=False, newton=False, rescale=False) -> int:
+    return ((A.HK_STAGE_SHIFT if shift else 0) | (A.HK_STAGE_REPOSITION if reposition else 0)
+            | (A.HK_STAGE_NEWTON if newton else 0) | (A.HK_STAGE_RESCALE if rescale else 0))
+
+
+def _require_device(t: torch.Tensor, name: str) -> None:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor on a HIP device. Got {type(t)}.")
+    if not t.is_cuda:
+        raise TypeError(f"{name} must live on a HIP device (hironaka_amd has no CPU path). Got {t.device}.")
+
+
+def _state(points: torch.Tensor, name="points") -> Tuple[torch.Tensor, torch.dtype]:
+    """contiguous f32/f64 view of the state + the dtype to hand back"""
+    _require_device(points, name)
+    orig = points.dtype
+    if orig in (torch.float16, torch.bfloat16):
+        points = points.float()
+    elif orig not in (torch.float32, torch.float64):
+        raise TypeError(f"{name} must be a floating tensor. Got {orig}.")
+    return points.contiguous(), orig
+
+
+def _stream(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _aux(t: Optional[torch.Tensor], like: torch.Tensor, name: str) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(t, device=like.device)
+    _require_device(t, name)
+    if t.device != like.device:
+        raise ValueError(f"{name} is on {t.device}, points on {like.device}")
+    if t.dtype in (torch.float16, torch.bfloat16):
+        t = t.float()
+    if t.dtype == torch.bool:
+        t = t.to(torch.uint8)
+    if t.dtype not in _TORCH2HK:
+        raise TypeError(f"{name}: unsupported dtype {t.dtype}")
+    return t.contiguous()
+
+
+def step(points: torch.Tensor, coords=None, axis=None, *, stages: int, flags: int = 0,
+         padding_value: float = -1.0, reward_sign: float = 1.0, spec: Optional[Tuple[int, int]] = None,
+         coords_in_record: bool = False, out: Optional[torch.Tensor] = None,
+         want: Sequence[str] = ()) -> Dict[str, torch.Tensor]:
+    """One fused transition (hk_step).
+
+    points: [B, m, d] state, or a [B, stride] record matrix with ``spec=(m, d)`` (flattened host
+        observation, or agent observation whose last d columns are the subset mask --
+        ``coords_in_record=True``; jax/util.py:58-74).
+    coords: [B, d] multi-binary mask (any numeric dtype) or [B] class ids (int32/int64).
+    axis: [B] int or float.
+    want: any of "done", "prev_done", "reward", "num_points".
+    Returns {"points": [B, m, d] (or `out`), ...}."""
+    pts, orig = _state(points)
+    if pts.dim() == 3:
+        b, m, d = pts.shape
+        in_stride = m * d
+    elif pts.dim() == 2 and spec is not None:
+        b, in_stride = pts.shape
+        m, d = spec
+    else:
+        raise ValueError("points must be [B, m, d], or [B, stride] together with spec=(m, d)")
+    dev = pts.device
+    s = A.hk_step_desc()
+    if out is None:
+        out_t = torch.empty((b, m, d), dtype=pts.dtype, device=dev)
+        out_stride = m * d
+    else:
+        _require_device(out, "out")
+        if out.dtype != pts.dtype or not out.is_contiguous() or out.shape[0] != b:
+            raise ValueError("out must be contiguous, of the state dtype and batch")
+        out_t = out
+        out_stride = out.numel() // max(b, 1)
+    keep = [pts, out_t]
+    s.points_in, s.points_out = pts.data_ptr(), out_t.data_ptr()
+    s.in_stride, s.out_stride = in_stride, out_stride
+    s.coords_kind = A.HK_COORDS_NONE
+    if stages & A.HK_STAGE_SHIFT:
+        ax = _aux(axis, pts, "axis")
+        if ax is None or ax.shape != (b,):
+            raise ValueError(f"axis must have shape ({b},)")
+        if ax.dtype == torch.uint8:
+            ax = ax.to(torch.int32)
+        keep.append(ax)
+        s.axis, s.axis_dtype = ax.data_ptr(), _TORCH2HK[ax.dtype]
+        if coords_in_record:
+            s.coords_kind = A.HK_COORDS_IN_RECORD
+        else:
+            co = _aux(coords, pts, "coords")
+            if co is None:
+                raise ValueError("coords is required for the shift stage")
+            keep.append(co)
+            if co.dim() == 1:
+                if co.shape != (b,) or co.dtype not in (torch.int32, torch.int64):
+                    raise ValueError("class-id coords must be int32/int64 of shape (B,)")
+                s.coords_kind = A.HK_COORDS_CLASS_I32 if co.dtype == torch.int32 else A.HK_COORDS_CLASS_I64
+            elif co.shape == (b, d):
+                s.coords_kind = _TORCH2HK[co.dtype]
+                s.coords_stride = d
+            else:
+                raise ValueError(f"coords must have shape ({b}, {d}) or ({b},)")
+            s.coords = co.data_ptr()
+    res: Dict[str, torch.Tensor] = {}
+    for key in want:
+        if key in ("done", "prev_done"):
+            res[key] = torch.empty(b, dtype=torch.uint8, device=dev)
+        elif key == "reward":
+            res[key] = torch.empty(b, dtype=torch.float32, device=dev)
+        elif key == "num_points":
+            res[key] = torch.empty(b, dtype=torch.int32, device=dev)
+        else:
+            raise ValueError(f"unknown output {key}")
+    s.done_out = res["done"].data_ptr() if "done" in res else None
+    s.prev_done_out = res["prev_done"].data_ptr() if "prev_done" in res else None
+    s.reward_out = res["reward"].data_ptr() if "reward" in res else None
+    s.num_points_out = res["num_points"].data_ptr() if "num_points" in res else None
+    s.padding_value, s.reward_sign = float(padding_value), float(reward_sign)
+    s.batch, s.max_points, s.dim, s.dtype = b, m, d, _TORCH2HK[pts.dtype]
+    s.stages, s.flags = stages, flags
+    with torch.cuda.device(dev):
+        check(lib().hk_step(C.byref(s), _stream(pts)), "hk_step")
+    for key in ("done", "prev_done"):
+        if key in res:
+            res[key] = res[key].bool()
+    if out is None and orig != out_t.dtype:
+        out_t = out_t.to(orig)
+    res["points"] = out_t
+    return res
+
+
+def shift(points, coords, axis, padding_value: float = -1.0, sem: str = "jax", noop_if_invalid=False,
+          ignore_ended=False, **kw) -> torch.Tensor:
+    """shift_jax / shift_torch / shift_lst (see include/hironaka_hip.h)."""
+    return step(points, coords, axis, stages=A.HK_STAGE_SHIFT, padding_value=padding_value,
+                flags=make_flags(sem, noop_if_invalid, ignore_ended, **kw))["points"]
+
+
+def reposition(points, padding_value: float = -1.0, sem: str = "jax", **kw) -> torch.Tensor:
+    return step(points, stages=A.HK_STAGE_REPOSITION, padding_value=padding_value,
+                flags=make_flags(sem, **kw))["points"]
+
+
+def get_newton_polytope(points, padding_value: float = -1.0, sem: str = "jax", compact_sorted=False,
+                        **kw) -> torch.Tensor:
+    return step(points, stages=A.HK_STAGE_NEWTON, padding_value=padding_value,
+                flags=make_flags(sem, compact_sorted=compact_sorted, **kw))["points"]
+
+
+def rescale(points, padding_value: float = -1.0, sem: str = "jax", **kw) -> torch.Tensor:
+    return step(points, stages=A.HK_STAGE_RESCALE, padding_value=padding_value,
+                flags=make_flags(sem, **kw))["points"]
+
+
+def _counts(points: torch.Tensor, spec, fn_name: str, out_dtype) -> torch.Tensor:
+    pts, _ = _state(points)
+    if pts.dim() == 3:
+        b, m, d = pts.shape
+        stride = m * d
+    elif pts.dim() == 2 and spec is not None:
+        b, stride = pts.shape
+        m, d = spec
+    else:
+        raise ValueError("points must be [B, m, d], or [B, stride] together with spec=(m, d)")
+    out = torch.empty(b, dtype=out_dtype, device=pts.device)
+    with torch.cuda.device(pts.device):
+        check(getattr(lib(), fn_name)(pts.data_ptr(), stride, out.data_ptr(), b, m, d,
+                                      _TORCH2HK[pts.dtype], _stream(pts)), fn_name)
+    return out
+
+
+def get_dones(points: torch.Tensor, spec=None) -> torch.Tensor:
+    """(#rows with x_0 >= 0) < 2 -- jax/util.py:34-35."""
+    return _counts(points, spec, "hk_get_dones", torch.uint8).bool()
+
+
+def get_num_points(points: torch.Tensor, spec=None) -> torch.Tensor:
+    """core/tensor_points.py:65-70."""
+    return _counts(points, spec, "hk_get_num_points", torch.int32)
+
+
+def decode_host_class(cls: torch.Tensor, dim: int, dtype=torch.float32) -> torch.Tensor:
+    """class ids -> multi-binary masks (jax/host_action_preprocess.py:59-65)."""
+    _require_device(cls, "cls")
+    ids = cls.to(torch.int32).contiguous()
+    n_cls = 2 ** dim - dim - 1
+    out = torch.empty((ids.numel(), dim), dtype=dtype, device=ids.device)
+    if dtype not in _TORCH2HK:
+        raise TypeError(f"unsupported mask dtype {dtype}")
+    with torch.cuda.device(ids.device):
+        check(lib().hk_decode_host_class(ids.data_ptr(), out.data_ptr(), _TORCH2HK[dtype], ids.numel(), dim,
+                                         _stream(ids)), "hk_decode_host_class")
+    return out.reshape(*cls.shape, dim)
+
+
+def zeillinger(points: torch.Tensor) -> torch.Tensor:
+    """Zeillinger host (jax/players.py:84-109): class id per game."""
+    pts, _ = _state(points)
+    b, m, d = pts.shape
+    out = torch.empty(b, dtype=torch.int32, device=pts.device)
+    with torch.cuda.device(pts.device):
+        check(lib().hk_zeillinger(pts.data_ptr(), m * d, out.data_ptr(), b, m, d, _TORCH2HK[pts.dtype],
+                                  _stream(pts)), "hk_zeillinger")
+    return out
+
+
+def get_features(points: torch.Tensor, scale_observation: bool = True, padding_value: float = -1.0,
+                 spec=None) -> torch.Tensor:
+    """order_and_rescale (jax/util.py:186-197): [B, m*d] rows sorted descending, last coordinate
+    primary, optionally rescaled first."""
+    pts, orig = _state(points)
+    if pts.dim() == 3:
+        b, m, d = pts.shape
+        in_stride = m * d
+    else:
+        b, in_stride = pts.shape
+        m, d = spec
+    out = torch.empty((b, m * d), dtype=pts.dtype, device=pts.device)
+    with torch.cuda.device(pts.device):
+        check(lib().hk_get_features(pts.data_ptr(), in_stride, out.data_ptr(), m * d, b, m, d,
+                                    _TORCH2HK[pts.dtype], int(bool(scale_observation)), float(padding_value),
+                                    _stream(pts)), "hk_get_features")
+    return out if orig == out.dtype else out.to(orig)
+
+
+def generate_points(batch: int, max_points: int, dim: int, max_value: int, seed: int, *,
+                    game_offset: int = 0, dtype=torch.float32, device=None, newton=True, reposition=True,
+                    rescale=False, padding_value: float = -1.0, flags: int = 0,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """generate_pts (jax/util.py:385-392): randint[0, max_value) -> newton -> [reposition] ->
+    [rescale], Philox-keyed by (seed, game_offset + game index)."""
+    if out is None:
+        device = torch.device("cuda") if device is None else torch.device(device)
+        if device.type != "cuda":
+            raise TypeError("generate_points needs a HIP device")
+        out = torch.empty((batch, max_points, dim), dtype=dtype, device=device)
+    else:
+        _require_device(out, "out")
+    stages = make_stages(False, reposition, newton, rescale)
+    with torch.cuda.device(out.device):
+        check(lib().hk_generate_points(out.data_ptr(), batch, max_points, dim, _TORCH2HK[out.dtype], max_value,
+                                       seed, game_offset, stages, float(padding_value), flags, _stream(out)),
+              "hk_generate_points")
+    return out
+
+
+def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0, step_offset: int = 0,
+            host_policy: int = A.HK_HOST_RANDOM, agent_policy: int = A.HK_AGENT_RANDOM,
+            stages: int = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON, flags: int = 0,
+            padding_value: float = -1.0, reward_sign: float = 1.0, record: Sequence[str] = (),
+            done_count: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """T fused steps with in-kernel policies (hk_rollout); `points` is updated IN PLACE.
+    record: any of "obs", "host_class", "axis", "done", "reward", "game_length".
+    done_count: optional uint64-as-int64 [steps+1] accumulator (zeroed by the caller)."""
+    _require_device(points, "points")
+    if points.dtype not in (torch.float32, torch.float64) or not points.is_contiguous() or points.dim() != 3:
+        raise ValueError("rollout updates a contiguous [B, m, d] float32/float64 tensor in place")
+    b, m, d = points.shape
+    dev = points.device
+    r = A.hk_rollout_desc()
+    res: Dict[str, torch.Tensor] = {}
+    if done_count is None:
+        done_count = torch.zeros(steps + 1, dtype=torch.int64, device=dev)
+    elif done_count.dtype != torch.int64 or done_count.numel() != steps + 1 or not done_count.is_cuda:
+        raise ValueError("done_count must be an int64 device tensor of steps+1 elements")
+    res["done_count"] = done_count
+    for key in record:
+        if key == "obs":
+            res[key] = torch.empty((steps, b, m, d), dtype=points.dtype, device=dev)
+        elif key in ("host_class", "axis"):
+            res[key] = torch.empty((steps, b), dtype=torch.int32, device=dev)
+        elif key == "done":
+            res[key] = torch.empty((steps, b), dtype=torch.uint8, device=dev)
+        elif key == "reward":
+            res[key] = torch.empty((steps, b), dtype=torch.float32, device=dev)
+        elif key == "game_length":
+            res[key] = torch.empty(b, dtype=torch.int32, device=dev)
+        else:
+            raise ValueError(f"unknown record {key}")
+    ptr = lambda k: res[k].data_ptr() if k in res else None
+    r.points, r.done_count = points.data_ptr(), done_count.data_ptr()
+    r.obs_out, r.host_class_out, r.axis_out = ptr("obs"), ptr("host_class"), ptr("axis")
+    r.done_out, r.reward_out, r.game_length_out = ptr("done"), ptr("reward"), ptr("game_length")
+    r.seed, r.game_offset, r.step_offset = seed, game_offset, step_offset
+    r.padding_value, r.reward_sign = float(padding_value), float(reward_sign)
+    r.batch, r.max_points, r.dim, r.dtype, r.steps = b, m, d, _TORCH2HK[points.dtype], steps
+    r.host_policy, r.agent_policy, r.stages, r.flags = host_policy, agent_policy, stages, flags
+    with torch.cuda.device(dev):
+        check(lib().hk_rollout(C.byref(r), _stream(points)), "hk_rollout")
+    if "done" in res:
+        res["done"] = res["done"].bool()
+    res["points"] = points
+    return res
+
+
+def has_fast_path(max_points: int, dim: int, dtype=torch.float32) -> bool:
+    return bool(lib().hk_has_fast_path(max_points, dim, _TORCH2HK.get(dtype, -1)))

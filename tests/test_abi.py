@@ -1,0 +1,93 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads without
+a GPU and exports every symbol include/hironaka_hip.h declares; the python mirror of the header
+agrees with it; the product never imports the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from hironaka_amd import _abi as A
+from hironaka_amd import _lib
+
+
+def _header():
+    with open(os.path.join(ROOT, "include", "hironaka_hip.h")) as f:
+        return f.read()
+
+
+def test_library_exports_every_declared_symbol():
+    _lib.build()
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(hk_\w+)\(", _header(), flags=re.M))
+    assert declared == set(A.PROTOTYPES), declared ^ set(A.PROTOTYPES)
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert _lib.lib().hk_abi_version() == A.HK_ABI_VERSION
+    assert _lib.lib().hk_strerror(A.HK_ERR_SHAPE).decode().startswith("batch")
+
+
+def test_python_constants_match_header():
+    text = _header()
+    for name, value in re.findall(r"#define\s+(HK_\w+)\s+\(?(-?\d+)u?\)?\s", text):
+        assert getattr(A, name) == int(value), name
+
+
+def test_descriptor_layout_matches_c():
+    """sizeof/offsetof as the C compiler sees them (gcc on the header) == ctypes."""
+    import subprocess, tempfile
+    fields = {"hk_step_desc": [f[0] for f in A.hk_step_desc._fields_],
+              "hk_rollout_desc": [f[0] for f in A.hk_rollout_desc._fields_]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "hironaka_hip.h"', 'int main(){']
+    for st, fl in fields.items():
+        src.append(f'printf("{st} %zu\\n", sizeof({st}));')
+        for f in fl:
+            src.append(f'printf("{st}.{f} %zu\\n", offsetof({st}, {f}));')
+    src.append('return 0;}')
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "layout.c")
+        open(c, "w").write("\n".join(src))
+        exe = os.path.join(td, "layout")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        out = subprocess.check_output([exe]).decode().split("\n")
+    got = dict(line.split() for line in out if line)
+    for st, cls in (("hk_step_desc", A.hk_step_desc), ("hk_rollout_desc", A.hk_rollout_desc)):
+        assert int(got[st]) == ctypes.sizeof(cls)
+        for f in fields[st]:
+            assert int(got[f"{st}.{f}"]) == getattr(cls, f).offset, (st, f)
+
+
+def test_argument_validation_without_gpu():
+    """status codes for bad arguments are decided on the host, before any launch"""
+    L = _lib.lib()
+    s = A.hk_step_desc()
+    s.batch, s.max_points, s.dim, s.dtype = 4, 0, 3, A.HK_F32
+    assert L.hk_step(ctypes.byref(s), None) == A.HK_ERR_SHAPE
+    s.max_points = 5
+    assert L.hk_step(ctypes.byref(s), None) == A.HK_ERR_NULL
+    s.dtype = A.HK_I32
+    assert L.hk_step(ctypes.byref(s), None) == A.HK_ERR_UNSUPPORTED
+    assert L.hk_step(None, None) == A.HK_ERR_NULL
+    assert L.hk_generate_points(None, 0, 5, 3, A.HK_F32, 10, 1, 0, 0, -1.0, 0, None) == A.HK_OK  # empty batch
+    assert L.hk_generate_points(None, 8, 5, 3, A.HK_F32, 10, 1, 0, 0, -1.0, 0, None) == A.HK_ERR_NULL
+    assert L.hk_has_fast_path(20, 3, A.HK_F32) == 1 and L.hk_has_fast_path(21, 3, A.HK_F32) == 0
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "hironaka_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), fn
+                assert "libhironaka_oracle" not in text and "np_oracle" not in text, fn
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from hironaka_amd import ops
+    with pytest.raises(TypeError):
+        ops.get_newton_polytope(torch.zeros(2, 4, 3))
+    with pytest.raises(TypeError):
+        ops.get_dones(torch.zeros(2, 4, 3))

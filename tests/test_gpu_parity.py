@@ -1,0 +1,385 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle, the hand-typed
+known answers and the committed outputs of the reference's torch / list siblings.
+
+Bit-exact (np.array_equal) everywhere except where the reference itself only pins a tolerance
+(rescale vs 4-digit printouts) -- stated at the assertion.
+"""
+import numpy as np
+import pytest
+import torch
+
+from hironaka_amd import _abi as A
+from hironaka_amd import ops
+from oracle import c_oracle as CO
+from oracle import np_oracle as NO
+
+pytestmark = pytest.mark.gpu
+
+FAST_SPECS = [(4, 3), (4, 4), (5, 3), (6, 3), (8, 3), (10, 3), (16, 3), (20, 3), (8, 4), (20, 4), (50, 4)]
+GENERIC_SPECS = [(7, 3), (5, 2), (6, 5), (12, 6), (3, 3), (64, 3)]
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def f32(x):
+    return np.array(x, dtype=np.float32)
+
+
+def rand_state(rng, b, m, d, dtype=np.float32, pad=-1.0, maxv=6, holes=0.3):
+    p = rng.integers(0, maxv, (b, m, d)).astype(dtype)
+    p[rng.random((b, m)) < holes] = pad
+    return p
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+# ------------------------------------------------------------------------------------------
+# known answers from the reference's tests, through both kernel families
+# ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("force_generic", [False, True])
+@pytest.mark.parametrize("sem", ["jax", "torch"])
+def test_reference_sequence(golden, sem, force_generic):
+    kw = dict(sem=sem, force_generic=force_generic)
+    r = ops.get_newton_polytope(dev(f32(golden["newton_r"]["points"])), **kw)
+    assert np.array_equal(host(r), f32(golden["newton_r"]["expected"]))
+    e = golden["shift_then_newton_r2"]
+    r2 = ops.get_newton_polytope(ops.shift(r, dev(np.array(e["coords"])), dev(np.array(e["axis"])), **kw), **kw)
+    assert np.array_equal(host(r2), f32(e["expected"]))
+    r3 = ops.reposition(r2, **kw)
+    assert np.array_equal(host(r3), f32(golden["reposition_r3"]["expected"]))
+    rs = ops.rescale(r3, **kw)
+    # the reference pins rs only to isclose / 4 printed digits (test/testJAX.py:172)
+    assert np.allclose(host(rs), f32(golden["rescale_rs"]["expected"]), atol=1e-6)
+    assert np.array_equal(host(rs), CO.rescale(host(r3), sem=sem))  # and bit-exact vs the oracle
+
+
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_reference_edge_cases(golden, force_generic):
+    for key in ("newton_extreme", "torch_functions_2", "torch_remove_repeated"):
+        e = golden[key]
+        for sem in ("jax", "torch"):
+            out = ops.get_newton_polytope(dev(f32(e["points"])), sem=sem, force_generic=force_generic)
+            assert np.array_equal(host(out), f32(e["expected"])), key
+    e = golden["rescale_s"]
+    assert np.array_equal(host(ops.rescale(dev(f32(e["points"])), force_generic=force_generic)), f32(e["expected"]))
+    e = golden["shift_fractional"]
+    out = ops.shift(dev(f32(e["points"])), dev(np.array(e["coords"])), dev(np.array(e["axis"])),
+                    force_generic=force_generic)
+    assert np.array_equal(host(out), f32(e["expected"]))
+    e = golden["torch_rescale_by_0"]
+    assert np.isfinite(host(ops.rescale(dev(f32(e["points"])), sem="torch", force_generic=force_generic))).all()
+    # torch semantics: illegal axis / finished game are no-ops (test/testTensorPoints.py:84-103)
+    e = golden["torch_invalid_actions"]
+    out = ops.shift(dev(f32(e["points"])), dev(np.array([[0, 1, 0, 0], [1, 0, 1, 1]])), dev(np.array(e["axis"])),
+                    sem="torch", noop_if_invalid=True, ignore_ended=True, force_generic=force_generic)
+    assert np.array_equal(host(out), f32(e["expected"]))
+    e = golden["torch_ended_game"]
+    for ign, key in ((True, "expected_ignore_ended"), (False, "expected_forced")):
+        out = ops.shift(dev(f32(e["points"])), dev(np.array([[1, 1, 0, 0]])), dev(np.array(e["axis"])),
+                        sem="torch", noop_if_invalid=True, ignore_ended=ign, force_generic=force_generic)
+        assert np.array_equal(host(out), f32(e[key]))
+
+
+def test_take_actions_composition(golden):
+    """test/testJAX.py:461-488 through hk_step, host role and agent role (mask in the record)."""
+    e = golden["take_actions_inputs"]
+    p, c, a = f32(e["points"]), np.array(e["coords"]), f32(e["axis"])
+    st = A.HK_STAGE_SHIFT | A.HK_STAGE_NEWTON | A.HK_STAGE_RESCALE
+    out = ops.step(dev(p.reshape(2, -1)), dev(c), dev(a), stages=st, spec=(4, 3))["points"]
+    assert np.array_equal(host(out), NO.rescale(NO.get_newton_polytope(NO.shift(p, c, a))))
+    obs = NO.make_agent_obs(p, c)
+    res = ops.step(dev(obs), None, dev(a), stages=A.HK_STAGE_SHIFT | A.HK_STAGE_NEWTON, spec=(4, 3),
+                   coords_in_record=True, reward_sign=-1.0, want=("done", "prev_done", "reward"))
+    assert np.array_equal(host(res["points"]), NO.get_newton_polytope(NO.shift(p, c, a)))
+    assert np.array_equal(host(res["reward"]), NO.reward(host(res["done"]), host(res["prev_done"]), "agent"))
+
+
+def test_features_zeillinger_codec(golden):
+    e = golden["features_host"]
+    assert np.array_equal(host(ops.get_features(dev(f32(e["points"])), True)), f32(e["expected"]))
+    for key in ("features_agent_unscaled", "features_agent_scaled"):
+        e = golden[key]
+        obs = f32(e["obs"])
+        feat = host(ops.get_features(dev(obs), e["scale_observation"], spec=tuple(e["spec"])))
+        assert np.array_equal(np.concatenate([feat, obs[:, 9:]], axis=1), f32(e["expected"])), key
+    for key in ("zeillinger_slice", "zeillinger_padded"):
+        e = golden[key]
+        assert host(ops.zeillinger(dev(f32(e["points"])))).tolist() == e["expected_class"]
+    e = golden["zeillinger_batch"]
+    cls = ops.zeillinger(dev(f32(e["points"])))
+    assert np.array_equal(host(ops.decode_host_class(cls, 4, torch.int32)), np.array(e["expected_mask"]))
+    e = golden["codec_d3"]
+    assert np.array_equal(host(ops.decode_host_class(dev(np.arange(4, dtype=np.int32)), 3, torch.int32)),
+                          np.array(e["decode_table"]))
+
+
+# ------------------------------------------------------------------------------------------
+# committed outputs of the reference's torch and list siblings
+# ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_live_torch(live_torch, force_generic):
+    tags = sorted({k.split("/")[0] for k in live_torch.files if k.startswith("m")})
+    for tag in tags:
+        g = lambda k: live_torch[f"{tag}/{k}"]
+        pad = -1.0 if tag.endswith("pad1") else -1e-8
+        kw = dict(sem="torch", padding_value=pad, force_generic=force_generic)
+        p = dev(g("points"))
+        assert np.array_equal(host(ops.get_newton_polytope(p, **kw)), g("newton")), tag
+        assert np.array_equal(host(ops.reposition(p, **kw)), g("reposition")), tag
+        assert np.array_equal(host(ops.rescale(p, **kw)), g("rescale")), tag
+        mask, axis, cls = dev(g("mask")), dev(g("axis")), dev(g("class"))
+        for ign in (0, 1):
+            out = ops.shift(p, mask, axis, noop_if_invalid=True, ignore_ended=bool(ign), **kw)
+            assert np.array_equal(host(out), g(f"shift_ign{ign}")), (tag, ign)
+        # FusedGame.agent_move (trainer/fused_game.py:150-163) as ONE fused launch per variant
+        start = ops.get_newton_polytope(p, **kw)
+        fl = ops.make_flags("torch", True, True, force_generic=force_generic)
+        res = ops.step(start, cls, axis, stages=A.HK_STAGE_SHIFT | A.HK_STAGE_NEWTON, flags=fl, padding_value=pad,
+                       want=("done", "num_points"))
+        assert np.array_equal(host(res["points"]), g("game_unscaled")), tag
+        assert np.array_equal(host(res["done"]), g("game_ended")), tag
+        assert np.array_equal(host(res["num_points"]), g("game_num_points")), tag
+        res = ops.step(start, mask, axis.double(), flags=fl, padding_value=pad,
+                       stages=A.HK_STAGE_SHIFT | A.HK_STAGE_NEWTON | A.HK_STAGE_RESCALE)
+        assert np.array_equal(host(res["points"]), g("game_scaled")), tag
+
+
+def test_live_list(live_list):
+    for tag in ("m6_d4", "m10_d3", "m20_d3", "m5_d2"):
+        g = lambda k: live_list[f"{tag}/{k}"]
+        p = dev(g("points"))
+        assert np.array_equal(host(ops.get_newton_polytope(p, sem="list")), g("newton")), tag
+        assert np.array_equal(host(ops.reposition(p, sem="list")), g("reposition")), tag
+        assert np.array_equal(host(ops.rescale(p, sem="list")), g("rescale")), tag
+        sh = ops.shift(p, dev(g("shift_mask")), dev(g("shift_axis")), sem="list", noop_if_invalid=True)
+        assert np.array_equal(host(sh), g("shift")), tag
+        assert np.array_equal(host(ops.get_newton_polytope(sh, sem="list")), g("shift_newton")), tag
+
+
+@pytest.mark.parametrize("scale", [0, 1])
+def test_live_config1_trajectory(live_list, scale):
+    """BASELINE config 1 (dim 3, 10 points, 32 games, Zeillinger vs recorded random agent):
+    every state of the reference's GameHironaka run, replayed with one fused launch per move."""
+    states = live_list[f"game_scale{scale}/states"]
+    masks, axes = live_list[f"game_scale{scale}/masks"], live_list[f"game_scale{scale}/axes"]
+    p = ops.get_newton_polytope(dev(live_list[f"game_scale{scale}/start"]), sem="list")
+    if scale:
+        p = ops.rescale(p, sem="list")
+    assert np.array_equal(host(p), states[0])
+    st = A.HK_STAGE_SHIFT | A.HK_STAGE_NEWTON | (A.HK_STAGE_RESCALE if scale else 0)
+    fl = ops.make_flags("list", noop_if_invalid=True)
+    for t in range(len(masks)):
+        res = ops.step(p, dev(masks[t]), dev(axes[t]), stages=st, flags=fl, want=("done",))
+        p = res["points"]
+        assert np.array_equal(host(p), states[t + 1]), t
+    assert host(res["done"]).all()
+
+
+# ------------------------------------------------------------------------------------------
+# seeded random inputs against the C oracle: every mode, both kernel families
+# ------------------------------------------------------------------------------------------
+
+def _check_all_ops(rng, m, d, dtype, force_generic, b=97):
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    for sem in ("jax", "torch", "list"):
+        for pad in (-1.0, -1e-8, -2.5):
+            p = rand_state(rng, b, m, d, dtype, pad)
+            p[3, 1] = [-3.0] * d  # irregular padding rows, incl. a duplicated one
+            p[3, 2] = [-3.0] * d
+            if d > 1:
+                p[4, 0, 0] = -0.5  # a mixed-sign row
+            P = dev(p)
+            kw = dict(sem=sem, padding_value=pad, force_generic=force_generic)
+            for compact in (False, True):
+                got = host(ops.get_newton_polytope(P, compact_sorted=compact, **kw))
+                assert np.array_equal(got, CO.get_newton_polytope(p, pad, sem=sem, compact_sorted=compact)), (sem, pad, compact)
+            assert np.array_equal(host(ops.reposition(P, **kw)), CO.reposition(p, pad, sem=sem))
+            assert np.array_equal(host(ops.rescale(P, **kw)), CO.rescale(p, pad, sem=sem))
+            cls = rng.integers(0, 2 ** d - d - 1, b).astype(np.int32)
+            ax = rng.integers(0, d, b).astype(np.int32)
+            for noop in (False, True):
+                for ign in (False, True):
+                    want = CO.shift(p, cls, ax, pad, sem=sem, noop_if_invalid=noop, ignore_ended=ign)
+                    got = ops.shift(P, dev(cls), dev(ax), noop_if_invalid=noop, ignore_ended=ign, **kw)
+                    assert np.array_equal(host(got), want), (sem, pad, noop, ign)
+            fl = ops.make_flags(sem, force_generic=force_generic)
+            for stages in (A.HK_STAGE_SHIFT | A.HK_STAGE_NEWTON, 7, 15):
+                want = CO.step(p, cls, ax, stages=stages, flags=CO.flags_of(sem=sem), padding_value=pad, reward_sign=-1.0)
+                got = ops.step(P, dev(cls), dev(ax).to(tdt), stages=stages, flags=fl, padding_value=pad,
+                               reward_sign=-1.0, want=("done", "prev_done", "reward", "num_points"))
+                assert np.array_equal(host(got["points"]), want["points"]), (sem, pad, stages)
+                for k in ("done", "prev_done", "reward", "num_points"):
+                    assert np.array_equal(host(got[k]), want[k]), (k, sem, stages)
+    q = rand_state(rng, b, m, d, dtype, -1.0)
+    assert np.array_equal(host(ops.get_dones(dev(q))), CO.get_dones(q))
+    assert np.array_equal(host(ops.get_num_points(dev(q))), CO.get_num_points(q))
+
+
+@pytest.mark.parametrize("spec", FAST_SPECS)
+def test_random_vs_oracle_fast_specs(spec):
+    m, d = spec
+    assert ops.has_fast_path(m, d)
+    rng = np.random.default_rng(100 * m + d)
+    _check_all_ops(rng, m, d, np.float32, force_generic=False, b=97 if m < 50 else 70)
+
+
+@pytest.mark.parametrize("spec", GENERIC_SPECS + [(20, 3), (10, 3)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_random_vs_oracle_generic(spec, dtype):
+    m, d = spec
+    rng = np.random.default_rng(7 * m + d)
+    _check_all_ops(rng, m, d, dtype, force_generic=True, b=70 if m < 64 else 40)
+
+
+def test_fast_equals_generic_on_dense_games():
+    """all 20 points alive, distinct and mutually non-dominating is the worst case of the pair loop"""
+    rng = np.random.default_rng(1)
+    b, m, d = 256, 20, 3
+    base = np.stack([np.arange(m), m - 1 - np.arange(m), np.zeros(m)], axis=1).astype(np.float32)  # antichain
+    p = np.repeat(base[None], b, 0)
+    for g in range(b):
+        p[g] = p[g][rng.permutation(m)]
+        p[g, :, 2] = rng.integers(0, 3, m)
+    a = host(ops.get_newton_polytope(dev(p)))
+    assert np.array_equal(a, host(ops.get_newton_polytope(dev(p), force_generic=True)))
+    assert np.array_equal(a, CO.get_newton_polytope(p))
+
+
+def test_large_values_and_float_axis():
+    """values near 2^24 (exact f32 integers) and float-typed axis (test/testJAX.py:474)"""
+    rng = np.random.default_rng(3)
+    p = (rng.integers(0, 1 << 22, (200, 20, 3))).astype(np.float32)
+    cls = rng.integers(0, 4, 200).astype(np.int64)
+    ax = rng.integers(0, 3, 200).astype(np.float32)
+    want = CO.step(p, cls, ax, stages=7)
+    got = ops.step(dev(p), dev(cls), dev(ax), stages=7)
+    assert np.array_equal(host(got["points"]), want["points"])
+
+
+# ------------------------------------------------------------------------------------------
+# generator, fused rollout, sharding
+# ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("spec,force_generic", [((20, 3), False), ((20, 3), True), ((10, 3), False), ((50, 4), False), ((7, 3), True)])
+def test_generate_matches_oracle(spec, force_generic):
+    m, d = spec
+    fl = A.HK_FLAG_FORCE_GENERIC if force_generic else 0
+    for resc in (False, True):
+        got = ops.generate_points(300, m, d, 20, seed=42, game_offset=11, rescale=resc, flags=fl)
+        want = CO.generate_points(300, m, d, 20, 42, 11, stages=A.HK_STAGE_NEWTON | A.HK_STAGE_REPOSITION | (A.HK_STAGE_RESCALE if resc else 0))
+        assert np.array_equal(host(got), want)
+    raw = ops.generate_points(300, m, d, 7, seed=1, newton=False, reposition=False, flags=fl)
+    assert np.array_equal(host(raw), NO.random_ints(300, m, d, 7, 1).astype(np.float32))
+
+
+@pytest.mark.parametrize("spec,force_generic", [((20, 3), False), ((20, 3), True), ((10, 3), False), ((8, 4), False), ((6, 5), True)])
+def test_rollout_matches_oracle(spec, force_generic):
+    m, d = spec
+    fl = A.HK_FLAG_FORCE_GENERIC if force_generic else 0
+    p0 = CO.generate_points(333, m, d, 20, 5)
+    for hp in (A.HK_HOST_RANDOM, A.HK_HOST_ALL_COORD, A.HK_HOST_ZEILLINGER):
+        for ap in (A.HK_AGENT_RANDOM, A.HK_AGENT_RANDOM_LEGAL, A.HK_AGENT_CHOOSE_FIRST, A.HK_AGENT_CHOOSE_LAST):
+            want_p, want = CO.rollout(p0, 9, 99, game_offset=17, step_offset=3, host_policy=hp, agent_policy=ap)
+            P = dev(p0.copy())
+            got = ops.rollout(P, 9, 99, game_offset=17, step_offset=3, host_policy=hp, agent_policy=ap, flags=fl,
+                              record=("obs", "host_class", "axis", "done", "reward", "game_length"))
+            assert np.array_equal(host(P), want_p), (hp, ap)
+            for k in ("obs", "host_class", "axis", "done", "reward", "game_length"):
+                assert np.array_equal(host(got[k]), want[k]), (k, hp, ap)
+            assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"])
+
+
+def test_rollout_equals_stepwise_launches():
+    """T fused steps == T single-step launches fed the recorded actions (the two bench paths)"""
+    P = ops.generate_points(4096, 20, 3, 20, seed=42)
+    Q = P.clone()
+    rec = ops.rollout(P, 12, 7, record=("host_class", "axis", "done"))
+    for t in range(12):
+        res = ops.step(Q, rec["host_class"][t], rec["axis"][t], stages=7, out=Q, want=("done",))
+        assert torch.equal(res["done"], rec["done"][t])
+    assert torch.equal(P, Q)
+
+
+def test_shard_invariance():
+    full = ops.generate_points(1000, 20, 3, 20, seed=3)
+    parts = [ops.generate_points(250, 20, 3, 20, seed=3, game_offset=250 * r) for r in range(4)]
+    assert torch.equal(full, torch.cat(parts))
+    ops.rollout(full, 10, 5)
+    for r in range(4):
+        ops.rollout(parts[r], 10, 5, game_offset=250 * r)
+    assert torch.equal(full, torch.cat(parts))
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE sizes: oracle on a slice + size-independent properties on the whole batch
+# ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("b,m,d", [(65536, 20, 3), (262144, 50, 4)])
+def test_baseline_sizes(b, m, d):
+    n_cls = 2 ** d - d - 1
+    P = ops.generate_points(b, m, d, 20, seed=42)
+    # generator output is a fixed point of newton and reposition (idempotence)
+    assert torch.equal(ops.get_newton_polytope(P), P)
+    assert torch.equal(ops.reposition(P), P)
+    npts = ops.get_num_points(P)
+    assert int(npts.min()) >= 1 and int(npts.max()) <= m
+    g = torch.Generator(device="cuda").manual_seed(0)
+    cls = torch.randint(0, n_cls, (b,), device="cuda", generator=g, dtype=torch.int32)
+    ax = torch.randint(0, d, (b,), device="cuda", generator=g, dtype=torch.int32)
+    res = ops.step(P, cls, ax, stages=7, want=("done", "prev_done", "reward", "num_points"))
+    Q = res["points"]
+    # oracle on the first / last 2048 games
+    for sl in (slice(0, 2048), slice(b - 2048, b)):
+        want = CO.step(host(P[sl]), host(cls[sl]), host(ax[sl]), stages=7)
+        assert np.array_equal(host(Q[sl]), want["points"])
+        assert np.array_equal(host(res["reward"][sl]), want["reward"])
+    # properties over the whole batch
+    assert torch.equal(ops.get_newton_polytope(Q), Q)           # result is reduced
+    assert torch.equal(res["num_points"], ops.get_num_points(Q))
+    assert torch.equal(res["done"], ops.get_dones(Q))
+    assert bool((res["num_points"] >= 1).all())                   # a game never loses its last point
+    assert bool((res["reward"] == (res["done"] & ~res["prev_done"]).float()).all())
+    # the specialised and the generic kernels agree on every game
+    assert torch.equal(Q, ops.step(P, cls, ax, stages=7, flags=A.HK_FLAG_FORCE_GENERIC)["points"])
+    # fused rollout: monotone done counts, every game that ends stays ended
+    rec = ops.rollout(P, 20, 1, record=("game_length",))
+    dc = host(rec["done_count"])
+    assert (np.diff(dc) >= 0).all() and dc[-1] == int(ops.get_dones(P).sum())
+    gl = host(rec["game_length"])
+    assert ((gl >= 0).sum() == dc[-1])
+
+
+# ------------------------------------------------------------------------------------------
+# error behaviour at the boundary
+# ------------------------------------------------------------------------------------------
+
+def test_error_behaviour():
+    from hironaka_amd._lib import HironakaHipError
+    P = torch.zeros(4, 5, 3, device="cuda")
+    with pytest.raises(ValueError):
+        ops.shift(P, torch.zeros(4, 2, device="cuda"), torch.zeros(4, device="cuda"))
+    with pytest.raises(ValueError):
+        ops.get_newton_polytope(P, sem="numpy")
+    with pytest.raises(TypeError):
+        ops.get_newton_polytope(P.int())
+    with pytest.raises(HironakaHipError) as ei:
+        ops.step(P.reshape(4, 15), None, None, stages=A.HK_STAGE_NEWTON, spec=(5, 4))
+    assert ei.value.status == A.HK_ERR_SHAPE
+    assert ops.get_newton_polytope(torch.zeros(0, 5, 3, device="cuda")).shape == (0, 5, 3)  # empty batch
+    h = torch.zeros(4, 5, 3, device="cuda", dtype=torch.float16)
+    assert ops.get_newton_polytope(h).dtype == torch.float16
