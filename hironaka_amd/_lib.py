@@ -7,6 +7,12 @@ import ctypes as C
 import os
 import subprocess
 
+# torch FIRST: it brings its own libamdhip64; loading ours afterwards resolves the HIP runtime to
+# that already-loaded copy, so kernels, streams and device pointers all live in ONE runtime.
+# (Loading libhironaka_hip.so first would pull /opt/rocm's runtime in beside torch's and every
+# launch on a torch stream would fail.)
+import torch  # noqa: F401
+
 from . import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -44,8 +44,9 @@ int launch_generic_t(const Params& prm, hipStream_t stream) {
     }
   }
   const unsigned grid = (unsigned)(((int64_t)prm.batch + prm.games_per_block - 1) / prm.games_per_block);
+  launch_prepare();
   hipLaunchKernelGGL(generic_kernel<T>, dim3(grid), dim3(kWave), lds, stream, prm);
-  return hipGetLastError() == hipSuccess ? HK_OK : HK_ERR_LAUNCH;
+  return launch_status();
 }
 
 int launch_generic(Params& prm, int dtype, hipStream_t stream) {
@@ -57,11 +58,16 @@ int launch_generic(Params& prm, int dtype, hipStream_t stream) {
 
 int launch(Params& prm, int dtype, hipStream_t stream) {
   if (prm.batch == 0) return HK_OK;
-  if (!(prm.flags & HK_FLAG_FORCE_GENERIC)) {
-    const int st = launch_fast(prm, dtype, stream);
-    if (st != HK_ERR_UNSUPPORTED) return st;
-  }
+  if (fast_supported(prm, dtype)) return launch_fast(prm, stream);
   return launch_generic(prm, dtype, stream);
+}
+
+// number of workgroups `launch` will use for this request (0: not launchable)
+int64_t planned_grid(Params prm, int dtype) {
+  if (prm.batch == 0) return 0;
+  if (fast_supported(prm, dtype)) return ((int64_t)prm.batch + kWave - 1) / kWave;
+  if (plan_generic(prm, dtype) != HK_OK) return 0;
+  return ((int64_t)prm.batch + prm.games_per_block - 1) / prm.games_per_block;
 }
 
 int valid_coords_kind(int kind) {
@@ -263,11 +269,13 @@ int hk_generate_points(void* points_out, int batch, int max_points, int dim, int
   return launch(prm, dtype, (hipStream_t)stream);
 }
 
-int hk_rollout(const hk_rollout_desc* r, void* stream) {
+static int params_from_rollout(const hk_rollout_desc* r, Params& prm) {
   if (!r) return HK_ERR_NULL;
   int st = check_spec(r->batch, r->max_points, r->dim, r->dtype);
   if (st != HK_OK) return st;
   if (r->steps < 0) return HK_ERR_SHAPE;
+  prm = Params{};
+  prm.batch = r->batch;
   if (r->batch == 0) return HK_OK;
   if (!r->points) return HK_ERR_NULL;
   if (r->dim < 2) return HK_ERR_SHAPE;  // the host needs a subset of >= 2 coordinates
@@ -277,12 +285,10 @@ int hk_rollout(const hk_rollout_desc* r, void* stream) {
   if (r->agent_policy < HK_AGENT_RANDOM || r->agent_policy > HK_AGENT_CHOOSE_LAST) return HK_ERR_UNSUPPORTED;
   if (r->stages & ~(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON | HK_STAGE_RESCALE)) return HK_ERR_UNSUPPORTED;
   if ((r->flags & HK_SEM_MASK) == HK_SEM_MASK) return HK_ERR_UNSUPPORTED;
-  Params prm{};
   prm.in = r->points;
   prm.out = r->points;
   prm.in_stride = prm.out_stride = (int64_t)r->max_points * r->dim;
   prm.coords_kind = HK_COORDS_NONE;
-  prm.done_count = (unsigned long long*)r->done_count;
   prm.obs_out = r->obs_out;
   prm.r_host_class_out = r->host_class_out;
   prm.r_axis_out = r->axis_out;
@@ -297,13 +303,37 @@ int hk_rollout(const hk_rollout_desc* r, void* stream) {
   prm.agent_policy = r->agent_policy;
   prm.pad = r->padding_value;
   prm.reward_sign = r->reward_sign;
-  prm.batch = r->batch;
   prm.m = r->max_points;
   prm.d = r->dim;
   prm.stages = r->stages;
   prm.flags = r->flags;
   prm.mode = kModeRollout;
-  return launch(prm, r->dtype, (hipStream_t)stream);
+  return HK_OK;
+}
+
+uint64_t hk_rollout_workspace_bytes(const hk_rollout_desc* r) {
+  Params prm{};
+  if (params_from_rollout(r, prm) != HK_OK || prm.batch == 0 || !r->done_count) return 0;
+  return (uint64_t)planned_grid(prm, r->dtype) * (uint64_t)(r->steps + 1) * sizeof(uint32_t);
+}
+
+int hk_rollout(const hk_rollout_desc* r, void* stream) {
+  Params prm{};
+  const int st = params_from_rollout(r, prm);
+  if (st != HK_OK) return st;
+  if (prm.batch == 0) return HK_OK;
+  const int64_t grid = planned_grid(prm, r->dtype);
+  if (grid == 0) return HK_ERR_UNSUPPORTED;
+  if (r->done_count) {
+    if (!r->workspace) return HK_ERR_NULL;
+    if (!aligned(r->workspace, 4)) return HK_ERR_ALIGN;
+    if (r->workspace_bytes < (uint64_t)grid * (uint64_t)(r->steps + 1) * sizeof(uint32_t)) return HK_ERR_SHAPE;
+    prm.count_ws = (uint32_t*)r->workspace;
+  }
+  const int ls = launch(prm, r->dtype, (hipStream_t)stream);
+  if (ls != HK_OK || !r->done_count) return ls;
+  return launch_count_reduce(prm.count_ws, (int)grid, r->steps, (unsigned long long*)r->done_count,
+                             (hipStream_t)stream);
 }
 
 int hk_zeillinger(const void* points, int64_t stride, int32_t* class_out, int batch,

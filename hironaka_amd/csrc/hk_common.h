@@ -37,7 +37,7 @@ struct Params {
   int32_t* num_points_out;
   int32_t* class_out;  // zeillinger operator
   // rollout
-  unsigned long long* done_count;
+  uint32_t* count_ws;  // [steps+1][gridDim.x] per-workgroup finished-game counts (or NULL)
   void* obs_out;
   int32_t* r_host_class_out;
   int32_t* r_axis_out;
@@ -64,6 +64,11 @@ struct Params {
   int32_t games_per_block;  // <= 64
   int32_t mode;
 };
+
+// hipGetLastError() is sticky per host thread and other users of the runtime in this process
+// (torch) leave benign errors behind: clear it right before a launch, read it right after.
+inline void launch_prepare() { (void)hipGetLastError(); }
+inline int launch_status() { return hipGetLastError() == hipSuccess ? HK_OK : HK_ERR_LAUNCH; }
 
 // ---- Philox4x32-10 ------------------------------------------------------------------------
 struct U4 {

@@ -355,9 +355,9 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
   if (mode == kModeGenerate) stages &= ~HK_STAGE_SHIFT;
   int np = active ? fast_num_points<M, D>(p) : 2;
   int length = (np < 2) ? 0 : -1;
-  if (mode == kModeRollout && prm.done_count) {
+  if (mode == kModeRollout && prm.count_ws) {
     const unsigned long long b0 = __ballot(active && np < 2);
-    if (lane == 0 && b0) atomicAdd(&prm.done_count[0], (unsigned long long)__popcll(b0));
+    if (lane == 0) prm.count_ws[blockIdx.x] = (uint32_t)__popcll(b0);
   }
   for (int t = 0; t < nsteps; ++t) {
     int axis = -1, cls = 0;
@@ -411,9 +411,9 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
         if (prm.r_done_out) prm.r_done_out[at] = done;
         if (prm.r_reward_out) prm.r_reward_out[at] = prm.reward_sign * (float)(done && !prev_done);
       }
-      if (prm.done_count) {
+      if (prm.count_ws) {
         const unsigned long long bd = __ballot(active && done);
-        if (lane == 0 && bd) atomicAdd(&prm.done_count[t + 1], (unsigned long long)__popcll(bd));
+        if (lane == 0) prm.count_ws[(size_t)(t + 1) * gridDim.x + blockIdx.x] = (uint32_t)__popcll(bd);
       }
     } else if (mode == kModeStep && active) {
       if (prm.done_out) prm.done_out[g] = done;
@@ -444,32 +444,73 @@ inline int has_fast_path(int m, int d, int dtype) {
   return 0;
 }
 
+// vector slab I/O needs W-aligned records
 template <int M, int D>
-int launch_fast_t(const Params& prm, hipStream_t stream) {
+bool fast_aligned_t(const Params& prm) {
   using G = FastGeom<M, D>;
   const size_t vec_bytes = G::W * 4;
-  // vector slab I/O needs W-aligned records
   if ((prm.in && (reinterpret_cast<uintptr_t>(prm.in) % vec_bytes)) ||
       (reinterpret_cast<uintptr_t>(prm.out) % vec_bytes) || (prm.in_stride % G::W) ||
       (prm.out_stride % G::W))
-    return HK_ERR_UNSUPPORTED;
-  if (prm.obs_out && (reinterpret_cast<uintptr_t>(prm.obs_out) % vec_bytes)) return HK_ERR_UNSUPPORTED;
-  const unsigned grid = (unsigned)(((int64_t)prm.batch + kWave - 1) / kWave);
-  hipLaunchKernelGGL((fast_kernel<M, D>), dim3(grid), dim3(kWave), 0, stream, prm);
-  return hipGetLastError() == hipSuccess ? HK_OK : HK_ERR_LAUNCH;
+    return false;
+  if (prm.obs_out && (reinterpret_cast<uintptr_t>(prm.obs_out) % vec_bytes)) return false;
+  return true;
 }
 
-// HK_ERR_UNSUPPORTED => caller falls back to the generic kernel
-inline int launch_fast(const Params& prm, int dtype, hipStream_t stream) {
-  if (dtype != HK_F32) return HK_ERR_UNSUPPORTED;
-  if ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)) return HK_ERR_UNSUPPORTED;
-  if (prm.stages & kStageFeatureSort) return HK_ERR_UNSUPPORTED;
-  if (prm.mode == kModeZeillinger) return HK_ERR_UNSUPPORTED;
-  if (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER) return HK_ERR_UNSUPPORTED;
+template <int M, int D>
+int launch_fast_t(const Params& prm, hipStream_t stream) {
+  const unsigned grid = (unsigned)(((int64_t)prm.batch + kWave - 1) / kWave);
+  launch_prepare();
+  hipLaunchKernelGGL((fast_kernel<M, D>), dim3(grid), dim3(kWave), 0, stream, prm);
+  return launch_status();
+}
+
+// does this request run on a register-resident specialisation? (else: generic kernel)
+inline bool fast_supported(const Params& prm, int dtype) {
+  if (dtype != HK_F32) return false;
+  if ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)) return false;
+  if (prm.flags & HK_FLAG_FORCE_GENERIC) return false;
+  if (prm.stages & kStageFeatureSort) return false;
+  if (prm.mode == kModeZeillinger) return false;
+  if (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER) return false;
+#define HK_X(M_, D_) if (prm.m == M_ && prm.d == D_) return fast_aligned_t<M_, D_>(prm);
+  HK_FAST_SPECS(HK_X)
+#undef HK_X
+  return false;
+}
+
+inline int launch_fast(const Params& prm, hipStream_t stream) {
 #define HK_X(M_, D_) if (prm.m == M_ && prm.d == D_) return launch_fast_t<M_, D_>(prm, stream);
   HK_FAST_SPECS(HK_X)
 #undef HK_X
   return HK_ERR_UNSUPPORTED;
+}
+
+// ---- finished-game counters: per-workgroup partials -> done_count ---------------------------------
+// block t sums count_ws[t][0..nblocks) and adds it to done_count[t]: steps+1 atomics in total
+// instead of (steps+1) * nblocks on one cache line.
+__global__ __launch_bounds__(256) void count_reduce_kernel(const uint32_t* ws, int nblocks,
+                                                           unsigned long long* done_count) {
+  __shared__ unsigned long long part[256 / kWave];
+  const uint32_t* row = ws + (size_t)blockIdx.x * nblocks;
+  unsigned long long s = 0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) s += row[i];
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) s += __shfl_down(s, off, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long tot = 0;
+    for (int w = 0; w < 256 / kWave; ++w) tot += part[w];
+    if (tot) atomicAdd(&done_count[blockIdx.x], tot);
+  }
+}
+
+inline int launch_count_reduce(const uint32_t* ws, int nblocks, int steps, unsigned long long* done_count,
+                               hipStream_t stream) {
+  launch_prepare();
+  hipLaunchKernelGGL(count_reduce_kernel, dim3(steps + 1), dim3(256), 0, stream, ws, nblocks, done_count);
+  return launch_status();
 }
 
 // ---- small utility kernels ------------------------------------------------------------------------
@@ -489,13 +530,14 @@ __global__ void counts_kernel(const T* points, int64_t stride, uint8_t* done_out
 inline int launch_counts(const void* points, int64_t stride, uint8_t* done_out, int32_t* num_out,
                          int batch, int m, int d, int dtype, hipStream_t stream) {
   const unsigned grid = (unsigned)((batch + 255) / 256);
+  launch_prepare();
   if (dtype == HK_F32)
     hipLaunchKernelGGL(counts_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)points,
                        stride, done_out, num_out, batch, m, d);
   else
     hipLaunchKernelGGL(counts_kernel<double>, dim3(grid), dim3(256), 0, stream, (const double*)points,
                        stride, done_out, num_out, batch, m, d);
-  return hipGetLastError() == hipSuccess ? HK_OK : HK_ERR_LAUNCH;
+  return launch_status();
 }
 
 __global__ void decode_kernel(const int32_t* cls, void* mask_out, int mask_dtype, int batch, int d) {
@@ -519,8 +561,9 @@ inline int launch_decode(const int32_t* cls, void* mask_out, int mask_dtype, int
                          hipStream_t stream) {
   const int64_t total = (int64_t)batch * d;
   const unsigned grid = (unsigned)((total + 255) / 256);
+  launch_prepare();
   hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(256), 0, stream, cls, mask_out, mask_dtype, batch, d);
-  return hipGetLastError() == hipSuccess ? HK_OK : HK_ERR_LAUNCH;
+  return launch_status();
 }
 
 }  // namespace hk

@@ -169,9 +169,9 @@ __global__ __launch_bounds__(kWave) void generic_kernel(const Params prm) {
   const uint64_t gg = prm.game_offset + (uint64_t)g;
   int np = active ? num_points(p, m, d) : 2;
   int length = (np < 2) ? 0 : -1;
-  if (prm.done_count) {
+  if (prm.count_ws) {
     const unsigned long long b0 = __ballot(active && np < 2);
-    if (lane == 0 && b0) atomicAdd(&prm.done_count[0], (unsigned long long)__popcll(b0));
+    if (lane == 0) prm.count_ws[blockIdx.x] = (uint32_t)__popcll(b0);
   }
   for (int t = 0; t < prm.steps; ++t) {
     if (prm.obs_out) {  // state before the step, coalesced
@@ -195,9 +195,9 @@ __global__ __launch_bounds__(kWave) void generic_kernel(const Params prm) {
       if (prm.r_done_out) prm.r_done_out[at] = done;
       if (prm.r_reward_out) prm.r_reward_out[at] = prm.reward_sign * (float)(done && !prev_done);
     }
-    if (prm.done_count) {
+    if (prm.count_ws) {
       const unsigned long long bd = __ballot(active && done);
-      if (lane == 0 && bd) atomicAdd(&prm.done_count[t + 1], (unsigned long long)__popcll(bd));
+      if (lane == 0) prm.count_ws[(size_t)(t + 1) * gridDim.x + blockIdx.x] = (uint32_t)__popcll(bd);
     }
     __syncthreads();
   }

@@ -289,6 +289,20 @@ def generate_points(batch: int, max_points: int, dim: int, max_value: int, seed:
     return out
 
 
+_WORKSPACES: Dict[Tuple[torch.device, int], torch.Tensor] = {}
+
+
+def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
+    """Per-(device, stream) scratch for hk_rollout's per-workgroup counters, grown on demand
+    (the C ABI never allocates; contents need no initialisation)."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
+        _WORKSPACES[key] = ws
+    return ws
+
+
 def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0, step_offset: int = 0,
             host_policy: int = A.HK_HOST_RANDOM, agent_policy: int = A.HK_AGENT_RANDOM,
             stages: int = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON, flags: int = 0,
@@ -330,6 +344,9 @@ def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0
     r.padding_value, r.reward_sign = float(padding_value), float(reward_sign)
     r.batch, r.max_points, r.dim, r.dtype, r.steps = b, m, d, _TORCH2HK[points.dtype], steps
     r.host_policy, r.agent_policy, r.stages, r.flags = host_policy, agent_policy, stages, flags
+    need = lib().hk_rollout_workspace_bytes(C.byref(r))
+    ws = _workspace(dev, need)
+    r.workspace, r.workspace_bytes = ws.data_ptr(), ws.numel()
     with torch.cuda.device(dev):
         check(lib().hk_rollout(C.byref(r), _stream(points)), "hk_rollout")
     if "done" in res:

@@ -136,7 +136,13 @@ typedef struct hk_step_desc {
 typedef struct hk_rollout_desc {
   void* points;           /* [batch, max_points*dim] state, updated in place              */
   uint64_t* done_count;   /* [steps+1] or NULL; += #finished games before step 0 and after
-                             each step (caller zeroes; accumulates across shards)          */
+                             each step (caller zeroes; accumulates across shards).  Needs
+                             `workspace`: per-workgroup partial counts are written there and
+                             summed by a second tiny kernel -- 1024 waves hitting one counter
+                             with atomics would serialise at ~10 ns each                    */
+  void* workspace;        /* device scratch of >= hk_rollout_workspace_bytes(desc) bytes, or
+                             NULL when done_count is NULL; contents need no initialisation  */
+  uint64_t workspace_bytes;
   void* obs_out;          /* [steps, batch, max_points*dim] or NULL: state before each step */
   int32_t* host_class_out; /* [steps, batch] or NULL: class id chosen by the host          */
   int32_t* axis_out;       /* [steps, batch] or NULL: axis chosen by the agent             */
@@ -192,6 +198,9 @@ int hk_generate_points(void* points_out, int batch, int max_points, int dim, int
 
 /* ---- fused T-step rollout with in-kernel fixed policies -------------------------------- */
 int hk_rollout(const hk_rollout_desc* desc, void* stream);
+/* bytes of `workspace` hk_rollout needs for this descriptor (0 if done_count is NULL or the
+ * descriptor is invalid); depends only on batch, steps, max_points, dim, dtype, flags.      */
+uint64_t hk_rollout_workspace_bytes(const hk_rollout_desc* desc);
 
 /* ---- fixed host policy as its own operator: class id per game -------------------------- */
 int hk_zeillinger(const void* points, int64_t stride, int32_t* class_out, int batch,

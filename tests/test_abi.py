@@ -20,7 +20,7 @@ def _header():
 def test_library_exports_every_declared_symbol():
     _lib.build()
     handle = ctypes.CDLL(_lib.LIB_PATH)
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(hk_\w+)\(", _header(), flags=re.M))
+    declared = set(re.findall(r"^(?:int|uint64_t|const char\*)\s+(hk_\w+)\(", _header(), flags=re.M))
     assert declared == set(A.PROTOTYPES), declared ^ set(A.PROTOTYPES)
     for name in declared:
         assert hasattr(handle, name), name
