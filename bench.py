@@ -3,27 +3,33 @@
 
 Workload (BASELINE.json configs[1]): dim=3, max_points=20, batch=65 536 games per GPU, float32,
 max_value=20, reposition on / rescale off (hironaka/jax/jax_config.yml), uniformly random host
-class and agent axis sampled INSIDE the kernel (Philox), episodes of T=20 steps from freshly
-generated states (generate_pts: randint -> newton -> reposition).
+class and agent axis sampled INSIDE the kernel (Philox), episodes of T=20 steps
+(max_length_game) from freshly generated states (generate_pts: randint -> newton -> reposition).
 
-One "step" = one pass of the hot path over the whole per-GPU batch = ONE kernel launch that reads
-the state from HBM, chooses the host subset and the agent axis, does shift -> reposition ->
-Newton polytope -> done, counts finished games and writes the state back to HBM.  Every 20 steps
-the episode restarts from the resident fresh states (a device-to-device copy, inside the timed
-region).  The launches of an episode are captured once into a hipGraph and replayed, so the
-python interpreter is not in the timed loop.  K steps are timed exactly (K//20 replays of the
-episode graph + one graph of K%20 steps).
+One "step" = one pass of the hot path over the whole per-GPU batch: host subset -> agent axis ->
+shift -> reposition -> Newton polytope -> done/reward for every one of the 65 536 games, finished
+games included (the reference steps them too).  The timed region runs EXACTLY K such steps as
+K//20 episodes of 20 steps (+ one shorter episode of K%20 steps); an episode is ONE launch of the
+fused rollout kernel hk::fast_kernel<20,3,rollout> (SURVEY.md section 7 stage 5): the state is
+read from HBM once, stays in registers for the 20 steps and is written back once.  Before each
+episode the resident fresh states are copied over the working state (device-to-device, inside the
+timed region) and after it the per-step finished-game counts are reduced (second tiny kernel).
+Launches are captured once into hipGraphs and replayed, so python is not in the timed loop.
 
 N>1: one process per GPU (torch.distributed, backend nccl = RCCL), games sharded by rank
 (game_offset = rank*batch), no collective in the data path; one all-gather of the final states at
 the end of the timed region (the trainer boundary).  value = steps of ALL ranks / max time.
 
-Also reported on the same JSON line:
-  roofline      dominant kernel (fast_kernel<20,3>): algorithmic bytes per launch / mean launch
-                time from HIP events around the timed region
+Also on the JSON line:
+  roofline      the rollout kernel: algorithmic bytes per launch (501 B per env-step, SURVEY.md
+                8(d), x 65 536 games x 20 steps) / mean launch time from HIP events around the
+                timed region.  Because the state never leaves the registers between steps the
+                kernel's real HBM traffic is ~1/20 of the algorithmic figure, so `frac` can exceed
+                1; `traffic` carries the measured bytes when a PMC profile is available.
+  single_step   the same workload as one launch per env step (state through HBM every step: the
+                take_actions-shaped drop-in), with its own algorithmic-bytes roofline figure.
   cpu_baseline  the scalar C/OpenMP oracle (oracle/hironaka_oracle.c) on this box's host cores,
-                same workload, bounded sample (rank 0, N=1 only)
-  fused_rollout the same 20-step episodes as ONE launch each (state stays in registers)
+                same episodes, bounded sample (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -35,12 +41,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
 import torch
 import torch.distributed as dist
 
 DIM, MAX_POINTS, BATCH, MAX_VALUE, EPISODE = 3, 20, 65536, 20, 20
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+SEED = 7
 
 
 def algorithmic_bytes_per_step(m: int, d: int) -> int:
@@ -48,55 +54,41 @@ def algorithmic_bytes_per_step(m: int, d: int) -> int:
     return 2 * m * d * 4 + 4 * d + 4 + 4 + 1
 
 
-def capture_episode(ops, A, state, fresh, done_count, n_steps, seed, game_offset, stages):
-    """hipGraph of: state <- fresh ; n_steps x (one-step launch with in-kernel policies)."""
+def capture(fn):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        state.copy_(fresh)
-        for t in range(n_steps):
-            ops.rollout(state, 1, seed, game_offset=game_offset, step_offset=t, stages=stages,
-                        host_policy=A.HK_HOST_RANDOM, agent_policy=A.HK_AGENT_RANDOM,
-                        done_count=done_count[t:t + 2])
-    return g
-
-
-def capture_fused(ops, A, state, fresh, done_count, n_steps, seed, game_offset, stages):
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        state.copy_(fresh)
-        ops.rollout(state, n_steps, seed, game_offset=game_offset, stages=stages,
-                    host_policy=A.HK_HOST_RANDOM, agent_policy=A.HK_AGENT_RANDOM,
-                    done_count=done_count[: n_steps + 1])
+        fn()
     return g
 
 
 def cpu_baseline(seconds: float = 12.0):
-    """C/OpenMP oracle on the host cores: same episodes (64k games x 20 steps), repeated until
-    `seconds` of CPU work were timed."""
+    """C/OpenMP oracle on the host cores: the same episodes (64k games x 20 steps), repeated
+    until `seconds` of CPU work were timed."""
     from oracle import c_oracle as CO
     from hironaka_amd import _abi as A
     threads = CO.set_threads(0)
     fresh = CO.generate_points(BATCH, MAX_POINTS, DIM, MAX_VALUE, 42)
-    CO.rollout(fresh[:4096], EPISODE, 7, record=False)  # warm-up
+    stages = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON
+    CO.rollout(fresh[:4096], EPISODE, SEED, record=False, stages=stages)  # warm-up
     done, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        CO.rollout(fresh, EPISODE, 7, record=False,
-                   stages=A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON)
+        CO.rollout(fresh, EPISODE, SEED, record=False, stages=stages)
         done += BATCH * EPISODE
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": f"{done // (BATCH * EPISODE)} episodes of {BATCH} games x {EPISODE} steps "
                       f"({dt:.1f} s) with oracle/hironaka_oracle.c (scalar C + OpenMP, {threads} threads "
-                      f"of {os.cpu_count()} cores)"}
+                      f"on {os.cpu_count()} logical cores)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--batch", type=int, default=BATCH, help="games per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-step", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,15 +111,30 @@ def main():
     fresh = ops.generate_points(b, m, d, MAX_VALUE, seed=42, game_offset=game_offset)
     state = torch.empty_like(fresh)
     done_count = torch.zeros(EPISODE + 1, dtype=torch.int64, device="cuda")
+    step_counts = torch.zeros((EPISODE, 2), dtype=torch.int64, device="cuda")
     gathered = [torch.empty_like(state) for _ in range(world)] if distributed else None
     K, W = args.steps, args.warmup
     n_full, rem = divmod(K, EPISODE)
+    kw = dict(game_offset=game_offset, stages=stages, host_policy=A.HK_HOST_RANDOM,
+              agent_policy=A.HK_AGENT_RANDOM)
+
+    def episode(n_steps):
+        state.copy_(fresh)
+        ops.rollout(state, n_steps, SEED, done_count=done_count[: n_steps + 1], **kw)
+
+    def episode_stepwise(n_steps):
+        state.copy_(fresh)
+        for t in range(n_steps):
+            ops.rollout(state, 1, SEED, step_offset=t, done_count=step_counts[t], **kw)
 
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
-        g_episode = capture_episode(ops, A, state, fresh, done_count, EPISODE, 7, game_offset, stages)
-        g_rem = capture_episode(ops, A, state, fresh, done_count, rem, 7, game_offset, stages) if rem else None
-        g_fused = capture_fused(ops, A, state, fresh, done_count, EPISODE, 7, game_offset, stages)
+        episode(EPISODE)  # allocates the rollout workspace outside of any capture
+        episode_stepwise(1)
+        torch.cuda.synchronize()
+        g_episode = capture(lambda: episode(EPISODE))
+        g_rem = capture(lambda: episode(rem)) if rem else None
+        g_stepwise = None if args.no_single_step else capture(lambda: episode_stepwise(EPISODE))
     torch.cuda.synchronize()
 
     def barrier():
@@ -135,14 +142,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(n_full_, g_rem_):
-        for _ in range(n_full_):
-            g_episode.replay()
-        if g_rem_ is not None:
-            g_rem_.replay()
-
     # ---- warm-up (untimed) -------------------------------------------------------------------
-    run(max(1, W // EPISODE), None)
+    for _ in range(max(1, W // EPISODE)):
+        g_episode.replay()
     if distributed:
         dist.all_gather(gathered, state)
     barrier()
@@ -153,7 +155,10 @@ def main():
     barrier()
     t0 = time.perf_counter()
     ev0.record()
-    run(n_full, g_rem)
+    for _ in range(n_full):
+        g_episode.replay()
+    if g_rem is not None:
+        g_rem.replay()
     ev1.record()
     if distributed:
         dist.all_gather(gathered, state)
@@ -161,27 +166,39 @@ def main():
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream, around the K launches
+    region_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream, around the K steps
     if distributed:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    finished = int(done_count[EPISODE].item()) if n_full else 0
+    finished = int(done_count[EPISODE].item()) // max(1, n_full) if n_full else 0
 
-    # ---- fused-rollout variant (same episodes, one launch each), timed separately ---------
-    g_fused.replay()
-    barrier()
-    f0 = time.perf_counter()
-    for _ in range(max(1, n_full)):
-        g_fused.replay()
-    torch.cuda.synchronize()
-    fused_elapsed = time.perf_counter() - f0
-    fused_steps = max(1, n_full) * EPISODE
+    # ---- the one-launch-per-step variant, timed separately (rank 0's shard) --------------------
+    single = None
+    if g_stepwise is not None:
+        n_ep = max(1, min(n_full, 50))
+        g_stepwise.replay()
+        barrier()
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        for _ in range(n_ep):
+            g_stepwise.replay()
+        s1.record()
+        torch.cuda.synchronize()
+        step_s = s0.elapsed_time(s1) / 1e3 / (n_ep * EPISODE)
+        single = {"value": b / step_s, "unit": "env-steps/s per GPU", "us_per_step": step_s * 1e6,
+                  "steps": n_ep * EPISODE,
+                  "algorithmic_GBps": b * algorithmic_bytes_per_step(m, d) / step_s / 1e9,
+                  "frac_of_hbm_peak": b * algorithmic_bytes_per_step(m, d) / step_s / 1e9 / HBM_PEAK_GBS,
+                  "note": "one launch of hk::fast_kernel<20,3,rollout> (T=1) + counter reduce per env step; "
+                          "state read from and written to HBM every step"}
 
     if rank == 0:
         bytes_step = algorithmic_bytes_per_step(m, d)
-        launch_s = (kernel_ms / 1e3) / K
-        achieved = b * bytes_step / launch_s / 1e9
+        launches = n_full + (1 if rem else 0)
+        launch_s = (region_ms / 1e3) / max(1, launches)
+        steps_per_launch = K / max(1, launches)
+        achieved = b * bytes_step * steps_per_launch / launch_s / 1e9
         out = {
             "metric": "env-steps/sec at dim=3, max_pts=20, batch=65536; 1/2/4/8 GPUs",
             "value": world * b * K / elapsed,
@@ -196,30 +213,30 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"dim={d}, max_points={m}, batch={b} games per GPU (configs[1]), random host+agent "
-                            f"policies sampled in-kernel, reposition=True, rescale=False, episodes of {EPISODE} steps "
-                            f"from generate_pts states (max_value={MAX_VALUE}); 1 step = 1 launch, state through HBM",
+                "workload": f"dim={d}, max_points={m}, batch={b} games per GPU (BASELINE configs[1]), random "
+                            f"host+agent policies sampled in-kernel, reposition=True, rescale=False, episodes of "
+                            f"{EPISODE} steps from generate_pts states (max_value={MAX_VALUE}); fused rollout: "
+                            f"{EPISODE} env steps per launch",
                 "parallelism": f"{world} x independent game shards, all-gather of final states",
-                "launch": "hipGraph replay of 20-step episodes",
+                "launch": "hipGraph replay: d2d restore + rollout kernel + counter reduce per episode",
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": f"hk::fast_kernel<{m},{d}> (one env step of {b} games per launch)",
+                "kernel": f"hk::fast_kernel<{m},{d},rollout> ({b} games x {EPISODE} steps per launch)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
-                "algorithmic_bytes_per_launch": b * bytes_step,
+                "algorithmic_bytes_per_launch": int(b * bytes_step * steps_per_launch),
                 "mean_launch_us": launch_s * 1e6,
+                "note": "algorithmic = 501 B/env-step (SURVEY 8d) x games x steps; the fused kernel keeps the "
+                        "state in registers between steps, so real HBM traffic per launch is ~2*240 B/game",
             },
-            "fused_rollout": {
-                "value": world * b * fused_steps / fused_elapsed,
-                "unit": "env-steps/s",
-                "note": f"{EPISODE} steps per launch, state in registers; per-GPU shard timed on rank 0",
-            },
-            "games_finished_per_episode": finished // max(1, n_full),
+            "games_finished_per_episode": finished,
         }
+        if single is not None:
+            out["single_step"] = single
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
