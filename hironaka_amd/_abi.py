@@ -74,6 +74,7 @@ class hk_step_desc(C.Structure):
 class hk_rollout_desc(C.Structure):
     _fields_ = [
         ("points", C.c_void_p),
+        ("points_in", C.c_void_p),
         ("done_count", C.c_void_p),
         ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_uint64),

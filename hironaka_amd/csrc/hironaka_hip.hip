@@ -285,7 +285,8 @@ static int params_from_rollout(const hk_rollout_desc* r, Params& prm) {
   if (r->agent_policy < HK_AGENT_RANDOM || r->agent_policy > HK_AGENT_CHOOSE_LAST) return HK_ERR_UNSUPPORTED;
   if (r->stages & ~(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON | HK_STAGE_RESCALE)) return HK_ERR_UNSUPPORTED;
   if ((r->flags & HK_SEM_MASK) == HK_SEM_MASK) return HK_ERR_UNSUPPORTED;
-  prm.in = r->points;
+  if (r->points_in && !aligned(r->points_in, elem_size(r->dtype))) return HK_ERR_ALIGN;
+  prm.in = r->points_in ? r->points_in : r->points;
   prm.out = r->points;
   prm.in_stride = prm.out_stride = (int64_t)r->max_points * r->dim;
   prm.coords_kind = HK_COORDS_NONE;

@@ -62,11 +62,14 @@ __device__ inline int mask_pop(unsigned long long m) { return __popcll(m); }
 __device__ inline int mask_first(uint32_t m) { return __ffs(m) - 1; }
 __device__ inline int mask_first(unsigned long long m) { return __ffsll(m) - 1; }
 
-// wave-wide maximum of a small non-negative int, returned in an SGPR
-__device__ inline int wave_max(int v) {
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) v = max(v, __shfl_xor(v, off, kWave));
-  return __builtin_amdgcn_readfirstlane(v);
+// wave-wide maximum of a small int in [0, hi], returned in an SGPR: a downward search with one
+// ballot per candidate (scalar compares only) instead of a 6-deep chain of cross-lane shuffles whose
+// LDS-crossbar latency a lone wave per SIMD cannot hide.  From a previous maximum it ends after a
+// step or two.
+__device__ inline int wave_max(int v, int hi) {
+  int m = hi;
+  while (m > 0 && !__any(v >= m)) --m;
+  return m;
 }
 
 // ---- slab I/O ---------------------------------------------------------------------------------------
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
   // ---- 3. gather the live rows ------------------------------------------------------------------------
   float q[M * D];
   int np = mask_pop(gmask);
-  int nmax = wave_max(np);
+  int nmax = wave_max(np, M);
   gather_rows<M, D>(q, mine, gmask, nmax);
   if (!active) np = 2;  // never "done", never counted
   int length = (np < 2) ? 0 : -1;
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
       // (one ballot per step; the cross-lane maximum only when some game still fills all nmax rows)
       if (t + 1 < nsteps && !__any(active && np >= nmax)) {
         gmask = scatter_rows<M, D>(q, mine, gmask, nmax);
-        nmax = wave_max(active ? np : 0);
+        nmax = wave_max(active ? np : 0, nmax - 1);
         gather_rows<M, D>(q, mine, gmask, nmax);
       }
     } else if (MODE == kModeStep && active) {

@@ -307,15 +307,23 @@ def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0
             host_policy: int = A.HK_HOST_RANDOM, agent_policy: int = A.HK_AGENT_RANDOM,
             stages: int = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON, flags: int = 0,
             padding_value: float = -1.0, reward_sign: float = 1.0, record: Sequence[str] = (),
-            done_count: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+            done_count: Optional[torch.Tensor] = None,
+            initial: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """T fused steps with in-kernel policies (hk_rollout); `points` is updated IN PLACE.
     record: any of "obs", "host_class", "axis", "done", "reward", "game_length".
-    done_count: optional uint64-as-int64 [steps+1] accumulator (zeroed by the caller)."""
+    done_count: optional uint64-as-int64 [steps+1] accumulator (zeroed by the caller).
+    initial: optional tensor like `points` holding the starting state; it is left untouched and
+        `points` only receives the final state (an episode restart without a device copy)."""
     _require_device(points, "points")
     if points.dtype not in (torch.float32, torch.float64) or not points.is_contiguous() or points.dim() != 3:
         raise ValueError("rollout updates a contiguous [B, m, d] float32/float64 tensor in place")
     b, m, d = points.shape
     dev = points.device
+    if initial is not None:
+        _require_device(initial, "initial")
+        if (initial.shape != points.shape or initial.dtype != points.dtype or not initial.is_contiguous()
+                or initial.device != dev):
+            raise ValueError("initial must match points in shape, dtype, device and be contiguous")
     r = A.hk_rollout_desc()
     res: Dict[str, torch.Tensor] = {}
     if done_count is None:
@@ -338,6 +346,7 @@ def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0
             raise ValueError(f"unknown record {key}")
     ptr = lambda k: res[k].data_ptr() if k in res else None
     r.points, r.done_count = points.data_ptr(), done_count.data_ptr()
+    r.points_in = initial.data_ptr() if initial is not None else None
     r.obs_out, r.host_class_out, r.axis_out = ptr("obs"), ptr("host_class"), ptr("axis")
     r.done_out, r.reward_out, r.game_length_out = ptr("done"), ptr("reward"), ptr("game_length")
     r.seed, r.game_offset, r.step_offset = seed, game_offset, step_offset

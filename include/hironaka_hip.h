@@ -134,7 +134,10 @@ typedef struct hk_step_desc {
  * CPU oracle reproduces every action bit for bit and a sharded run equals the unsharded
  * one.                                                                                    */
 typedef struct hk_rollout_desc {
-  void* points;           /* [batch, max_points*dim] state, updated in place              */
+  void* points;           /* [batch, max_points*dim] final state (and, unless points_in is
+                             given, the initial state: updated in place)                   */
+  const void* points_in;  /* NULL, or [batch, max_points*dim] initial state, left untouched:
+                             an episode restart then costs no device-to-device copy        */
   uint64_t* done_count;   /* [steps+1] or NULL; += #finished games before step 0 and after
                              each step (caller zeroes; accumulates across shards).  Needs
                              `workspace`: per-workgroup partial counts are written there and

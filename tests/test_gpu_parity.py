@@ -313,6 +313,16 @@ def test_rollout_equals_stepwise_launches():
         res = ops.step(Q, rec["host_class"][t], rec["axis"][t], stages=7, out=Q, want=("done",))
         assert torch.equal(res["done"], rec["done"][t])
     assert torch.equal(P, Q)
+    # out-of-place variant: the initial state is read from `initial` and left untouched
+    fresh = ops.generate_points(4096, 20, 3, 20, seed=42)
+    keep = fresh.clone()
+    R = torch.empty_like(fresh)
+    ops.rollout(R, 12, 7, initial=fresh)
+    assert torch.equal(R, P) and torch.equal(fresh, keep)
+    for fl in (0, A.HK_FLAG_FORCE_GENERIC):
+        R.zero_()
+        ops.rollout(R, 12, 7, initial=fresh, flags=fl)
+        assert torch.equal(R, P)
 
 
 def test_shard_invariance():
