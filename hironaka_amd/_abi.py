@@ -120,7 +120,7 @@ PROTOTYPES = {
     "hk_generate_points": (C.c_int, [_vp, _i, _i, _i, _i, _i, _u64, _u64, _u32, _d, _u32, _vp]),
     "hk_rollout": (C.c_int, [C.POINTER(hk_rollout_desc), _vp]),
     "hk_rollout_workspace_bytes": (C.c_uint64, [C.POINTER(hk_rollout_desc)]),
-    "hk_zeillinger": (C.c_int, [_vp, _i64, _vp, _i, _i, _i, _i, _vp]),
+    "hk_zeillinger": (C.c_int, [_vp, _i64, _vp, _i, _i, _i, _i, _u32, _vp]),
     "hk_get_features": (C.c_int, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _d, _vp]),
     "hk_decode_host_class": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
 }

@@ -338,7 +338,7 @@ int hk_rollout(const hk_rollout_desc* r, void* stream) {
 }
 
 int hk_zeillinger(const void* points, int64_t stride, int32_t* class_out, int batch,
-                  int max_points, int dim, int dtype, void* stream) {
+                  int max_points, int dim, int dtype, uint32_t flags, void* stream) {
   int st = check_spec(batch, max_points, dim, dtype);
   if (st != HK_OK) return st;
   if (batch == 0) return HK_OK;
@@ -346,7 +346,9 @@ int hk_zeillinger(const void* points, int64_t stride, int32_t* class_out, int ba
   if (dim < 2) return HK_ERR_SHAPE;
   if (stride < (int64_t)max_points * dim) return HK_ERR_SHAPE;
   if (!aligned(points, elem_size(dtype)) || !aligned(class_out, 4)) return HK_ERR_ALIGN;
+  if ((flags & HK_SEM_MASK) != HK_SEM_JAX && (flags & HK_SEM_MASK) != HK_SEM_LIST) return HK_ERR_UNSUPPORTED;
   Params prm{};
+  prm.flags = flags;
   prm.in = points;
   prm.in_stride = stride;
   prm.out_stride = stride;

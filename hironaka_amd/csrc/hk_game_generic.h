@@ -242,6 +242,49 @@ __device__ inline int zeillinger_game(const T* p, int m, int d) {
   return encode_mask((1u << lo) | (1u << hi));
 }
 
+// Zeillinger._select_coord (host.py:70-95) on padded rows: pairs i<j of the available rows in row
+// order, key (L, S) = (max-min, #max + #min) of P_i - P_j, first minimum wins; the subset is
+// {argmin, argmax} of that difference, or {0, 1} if they coincide.  -1: fewer than 2 rows.
+template <typename T>
+__device__ inline int zeillinger_list_game(const T* p, int m, int d) {
+  T bestL = (T)0;
+  int bestS = 0, bi = -1, bj = -1;
+  for (int i = 0; i < m; ++i) {
+    if (!(p[i * d] >= (T)0)) continue;
+    for (int j = i + 1; j < m; ++j) {
+      if (!(p[j * d] >= (T)0)) continue;
+      T mx = p[i * d] - p[j * d], mn = mx;
+      for (int k = 1; k < d; ++k) {
+        const T v = p[i * d + k] - p[j * d + k];
+        mx = (v > mx) ? v : mx;
+        mn = (v < mn) ? v : mn;
+      }
+      int cnt = 0;
+      for (int k = 0; k < d; ++k) {
+        const T v = p[i * d + k] - p[j * d + k];
+        cnt += (v == mx) + (v == mn);
+      }
+      const T L = mx - mn;
+      if (bi < 0 || L < bestL || (L == bestL && cnt < bestS)) {
+        bestL = L;
+        bestS = cnt;
+        bi = i;
+        bj = j;
+      }
+    }
+  }
+  if (bi < 0) return -1;
+  int lo = 0, hi = 0;
+  T vlo = p[bi * d] - p[bj * d], vhi = vlo;
+  for (int k = 1; k < d; ++k) {
+    const T v = p[bi * d + k] - p[bj * d + k];
+    if (v < vlo) { vlo = v; lo = k; }
+    if (v > vhi) { vhi = v; hi = k; }
+  }
+  if (lo == hi) return encode_mask(3u);  // [0, 1]
+  return encode_mask((1u << lo) | (1u << hi));
+}
+
 // stable in-place insertion sort, descending, LAST coordinate primary (lexsort(-x^T))
 template <typename T>
 __device__ inline void feature_sort_game(T* p, int m, int d, T* row) {

@@ -140,7 +140,9 @@ __global__ __launch_bounds__(kWave) void generic_kernel(const Params prm) {
   __syncthreads();
 
   if (prm.mode == kModeZeillinger) {
-    if (active) prm.class_out[g] = zeillinger_game(p, m, d);
+    if (active)
+      prm.class_out[g] = ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST) ? zeillinger_list_game(p, m, d)
+                                                                     : zeillinger_game(p, m, d);
     return;
   }
 

@@ -1,0 +1,69 @@
+"""Multi-GPU: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" on CPU
+for tests), games sharded by rank, NO collective in the data path, one all-gather at the trainer
+boundary -- the counterpart of the reference's leading device axis under ``pmap`` and its host-side
+sums over that axis (hironaka/jax/jax_trainer.py:281-319, 513, 533-534).
+
+The Philox counters carry the GLOBAL game index, so ``generate`` / ``rollout`` with
+``game_offset = shard.start`` reproduce the unsharded batch bit for bit.
+"""
+from __future__ import annotations
+
+from typing import Dict, NamedTuple, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+class Shard(NamedTuple):
+    start: int  # global index of this rank's first game == game_offset
+    size: int   # games on this rank
+    total: int  # games over all ranks
+
+
+def world() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def shard_range(total_games: int, rank_: Optional[int] = None, world_: Optional[int] = None) -> Shard:
+    """contiguous, balanced split: the first (total % world) ranks own one game more"""
+    r = rank() if rank_ is None else rank_
+    w = world() if world_ is None else world_
+    base, extra = divmod(total_games, w)
+    size = base + (1 if r < extra else 0)
+    start = r * base + min(r, extra)
+    return Shard(start, size, total_games)
+
+
+def all_gather_games(local: torch.Tensor, shard: Optional[Shard] = None) -> torch.Tensor:
+    """[B_local, ...] per rank -> [B_total, ...] on every rank, in global game order.  Equal shards use
+    one all_gather_into_tensor; ragged shards are padded to the largest one first."""
+    w = world()
+    if w == 1:
+        return local
+    sizes = [shard_range(shard.total, r, w).size for r in range(w)] if shard is not None else None
+    if sizes is None or len(set(sizes)) == 1:
+        out = torch.empty((w * local.shape[0], *local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous())
+        return out
+    biggest = max(sizes)
+    padded = torch.zeros((biggest, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    out = torch.empty((w * biggest, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded)
+    return torch.cat([out[r * biggest: r * biggest + sizes[r]] for r in range(w)], dim=0)
+
+
+def all_gather_rollout(rollout: Sequence[torch.Tensor], shard: Optional[Shard] = None):
+    """(obs, policy, value) of each rank -> the full batch on every rank (trainer boundary)."""
+    return tuple(all_gather_games(x, shard) for x in rollout)
+
+
+def all_reduce_counts(counts: torch.Tensor) -> torch.Tensor:
+    """per-step finished-game counts summed over the ranks (jax_trainer.py:533-534)"""
+    if world() > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    return counts

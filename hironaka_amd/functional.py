@@ -1,0 +1,167 @@
+"""Functional environment API on device tensors -- the counterpart of the env part of
+``hironaka/jax/util.py`` (same names, same argument meaning, same error behaviour), backed by the
+HIP kernels through the C ABI.  What `recurrent_fn`, `compute_rho` and `search.py` call in the
+reference is what is exported here:
+
+    get_take_actions(role, spec, rescale_points=False, reposition=True) -> take_actions
+    take_actions(observations, actions, axis) -> [B, m*d]          one fused launch (hk_step)
+    get_dones, get_done_from_flatten, get_reward_fn, get_preprocess_fns, make_agent_obs, flatten,
+    get_feature_fn, generate_pts
+
+Differences forced by the platform: arrays are torch tensors on a HIP device; PRNG keys are integer
+seeds (Philox) instead of JAX threefry keys; there is no pmap -- one process per
+GPU, see ``hironaka_amd.distributed``.
+"""
+from __future__ import annotations
+
+import functools
+from typing import Callable, Optional, Tuple
+
+import torch
+
+from . import _abi as A
+from . import ops
+
+Rollout = Tuple[torch.Tensor, torch.Tensor, torch.Tensor]  # observations, policy logits, values
+
+
+def flatten(x: torch.Tensor) -> torch.Tensor:
+    """jax/util.py:19 -- [B, ...] -> [B, prod(...)]"""
+    return x.reshape(x.shape[0], -1)
+
+
+def make_agent_obs(pts: torch.Tensor, coords: torch.Tensor) -> torch.Tensor:
+    """jax/util.py:22-31 -- points flattened and concatenated with the host's subset mask."""
+    return torch.cat([flatten(pts), coords.to(pts.dtype)], dim=1)
+
+
+def get_dones(pts: torch.Tensor) -> torch.Tensor:
+    """jax/util.py:34-35 -- [B, m, d] -> [B] bool."""
+    return ops.get_dones(pts)
+
+
+def get_done_from_flatten(obs: torch.Tensor, role: str, dimension: int) -> torch.Tensor:
+    """jax/util.py:38-39 -- number of non-negative scalars <= d (+d for an agent observation)."""
+    return (obs >= 0).sum(dim=-1) <= dimension + (role == "agent") * dimension
+
+
+@functools.lru_cache()
+def get_preprocess_fns(role: str, spec: Tuple[int, int]) -> Tuple[Callable, Callable]:
+    """jax/util.py:43-79 -- (obs_preprocess, coords_preprocess) for flattened observations."""
+    m, d = spec
+    if role == "host":
+
+        def obs_preprocess(observations):
+            return observations.reshape(-1, m, d)
+
+        def coords_preprocess(observations, actions):
+            return actions
+
+    elif role == "agent":
+
+        def obs_preprocess(observations):
+            return observations[:, : m * d].reshape(-1, m, d)
+
+        def coords_preprocess(observations, actions):
+            return observations[:, m * d: m * d + d]
+
+    else:
+        raise ValueError(f"role must be either host or agent. Got {role}.")
+    return obs_preprocess, coords_preprocess
+
+
+@functools.lru_cache()
+def get_take_actions(role: str, spec: Tuple[int, int], rescale_points: bool = False,
+                     reposition: bool = True) -> Callable:
+    """jax/util.py:83-125.  role == 'host': observations = points ([B, m*d] or [B, m, d]), coords =
+    actions ([B, d] mask, or [B] class ids), axis = axis.  role == 'agent': observations =
+    concat(points, coords) [B, m*d + d], `actions` ignored, axis = axis.  Returns the new points
+    flattened to [B, m*d] (NOT the concatenated agent observation).  One hk_step launch."""
+    if role not in ("host", "agent"):
+        raise ValueError(f"role must be either host or agent. Got {role}.")
+    m, d = spec
+    stages = ops.make_stages(shift=True, reposition=reposition, newton=True, rescale=rescale_points)
+
+    def take_actions(observations: torch.Tensor, actions: Optional[torch.Tensor], axis: torch.Tensor,
+                     want=()):
+        if role == "host":
+            obs = observations if observations.dim() == 3 else observations.reshape(-1, m * d)
+            res = ops.step(obs, actions, axis, stages=stages, spec=None if obs.dim() == 3 else (m, d), want=want)
+        else:
+            res = ops.step(observations, None, axis, stages=stages, spec=(m, d), coords_in_record=True,
+                           want=want)
+        out = res["points"].reshape(-1, m * d)
+        if want:
+            res["points"] = out
+            return res
+        return out
+
+    return take_actions
+
+
+@functools.lru_cache()
+def get_reward_fn(role: str) -> Callable:
+    """jax/util.py:129-149 -- host: f32(done & ~prev_done); agent: its negative."""
+    if role == "host":
+
+        def reward_fn(dones: torch.Tensor, prev_dones: torch.Tensor) -> torch.Tensor:
+            return (dones & (~prev_dones)).to(torch.float32)
+
+    elif role == "agent":
+
+        def reward_fn(dones: torch.Tensor, prev_dones: torch.Tensor) -> torch.Tensor:
+            return -(dones & (~prev_dones)).to(torch.float32)
+
+    else:
+        raise ValueError(f"role must be either host or agent. Got {role}.")
+    return reward_fn
+
+
+@functools.lru_cache()
+def get_feature_fn(role: str, spec: Tuple[int, int], scale_observation: bool = True) -> Callable:
+    """jax/util.py:172-214 -- [rescale] + rows ordered descending (last coordinate primary); the
+    agent variant keeps the coordinate tail."""
+    assert len(spec) == 2
+    m, d = spec
+    if role == "host":
+
+        def feature_fn(observations: torch.Tensor) -> torch.Tensor:
+            obs = observations if observations.dim() == 3 else observations.reshape(-1, m * d)
+            return ops.get_features(obs, scale_observation, spec=None if obs.dim() == 3 else (m, d))
+
+    elif role == "agent":
+
+        def feature_fn(observations: torch.Tensor) -> torch.Tensor:
+            feats = ops.get_features(observations, scale_observation, spec=(m, d))
+            return torch.cat([feats, observations[:, m * d: m * d + d]], dim=1)
+
+    else:
+        raise ValueError(f"role must be either host or agent. Got {role}.")
+    return feature_fn
+
+
+def generate_pts(key: int, shape: Tuple[int, int, int], max_value: int, dtype=torch.float32,
+                 rescale: bool = True, reposition: bool = True, *, game_offset: int = 0,
+                 device=None) -> torch.Tensor:
+    """jax/util.py:385-392 -- randint[0, max_value) -> newton -> [reposition] -> [rescale].
+    `key` is an integer seed; `game_offset` is the global index of the first game (sharding)."""
+    batch, m, d = shape
+    return ops.generate_points(batch, m, d, max_value, int(key), game_offset=game_offset, dtype=dtype,
+                               device=device, newton=True, reposition=reposition, rescale=rescale)
+
+
+def rollout_sanity_tests(rollout: Rollout, spec: Tuple[int, int]) -> bool:
+    """jax/util.py:395-423 -- masks applied where the observation carries one; policy not a softmax."""
+    obs, policy, value = rollout
+    m, d = spec
+    if obs.shape[-1] == (m + 1) * d:
+        mask = obs[..., -d:] > 0.5
+        is_host = torch.isclose(mask.float(), torch.zeros((), device=obs.device)).all(dim=-1, keepdim=True)
+        full = torch.cat([mask | is_host, is_host.expand(*is_host.shape[:-1], policy.shape[-1] - d)], dim=-1)
+        masked_out = policy[~full]
+        if masked_out.numel() and not torch.isinf(masked_out).all():
+            return False
+    sums = policy.sum(dim=-1)
+    if torch.isclose(sums, torch.ones_like(sums)).all() and ((policy <= 1.0) & (policy >= 0.0)).all():
+        return False
+    return True

@@ -238,14 +238,17 @@ def decode_host_class(cls: torch.Tensor, dim: int, dtype=torch.float32) -> torch
     return out.reshape(*cls.shape, dim)
 
 
-def zeillinger(points: torch.Tensor) -> torch.Tensor:
-    """Zeillinger host (jax/players.py:84-109): class id per game."""
+def zeillinger(points: torch.Tensor, sem: str = "jax") -> torch.Tensor:
+    """Zeillinger host: class id per game.  sem="jax": jax/players.py:84-109 (degenerate -> 0);
+    sem="list": host.py:70-95 on padded rows (-1 for a game with fewer than 2 points)."""
+    if sem not in ("jax", "list"):
+        raise ValueError(f"sem must be 'jax' or 'list'. Got {sem}.")
     pts, _ = _state(points)
     b, m, d = pts.shape
     out = torch.empty(b, dtype=torch.int32, device=pts.device)
     with torch.cuda.device(pts.device):
         check(lib().hk_zeillinger(pts.data_ptr(), m * d, out.data_ptr(), b, m, d, _TORCH2HK[pts.dtype],
-                                  _stream(pts)), "hk_zeillinger")
+                                  A.SEMANTICS[sem], _stream(pts)), "hk_zeillinger")
     return out
 
 

@@ -1,0 +1,115 @@
+"""The environment half of the MCTS recurrent function -- the counterpart of
+``hironaka/jax/recurrent_fn.py`` with the same factory names, arguments and order of operations
+around the step (recurrent_fn.py:84-121, 161-197):
+
+    prev_dones -> (agent role: step first) -> opponent acts -> (host role: step) -> dones -> reward
+    -> role_fn(next_observations)
+
+The search driver that calls it in the reference (third-party ``mctx``) is out of scope; any search
+loop over torch tensors can call these functions.  ``mctx.RecurrentFnOutput`` is replaced by a
+NamedTuple with the same fields.
+"""
+from __future__ import annotations
+
+from typing import Callable, NamedTuple, Tuple
+
+import torch
+
+from .functional import flatten, get_dones, get_preprocess_fns, get_take_actions, make_agent_obs
+from .host_action_preprocess import get_batch_decode, get_batch_decode_from_one_hot, num_classes
+
+
+class RecurrentFnOutput(NamedTuple):
+    reward: torch.Tensor
+    discount: torch.Tensor
+    prior_logits: torch.Tensor
+    value: torch.Tensor
+
+
+def get_recurrent_fn_for_role(role: str, role_fn: Callable, opponent_action_fn: Callable, reward_fn: Callable,
+                              spec: Tuple[int, int], discount: float = 0.99, dtype=torch.float32,
+                              rescale_points: bool = False, reposition: bool = False) -> Callable:
+    """recurrent_fn.py:17-123.
+    role_fn(observations, *args, key=...) -> (policy_prior, value_prior) of the player under evaluation;
+    opponent_action_fn(observations, *args, key=...) -> one-hot actions of the fixed opponent;
+    reward_fn(dones, prev_dones) -> rewards."""
+    m, d = spec
+    obs_preprocess, _ = get_preprocess_fns(role, spec)
+    if role == "host":
+        take = get_take_actions(role="host", spec=spec, rescale_points=rescale_points, reposition=reposition)
+        batch_decode = get_batch_decode(d)
+    elif role == "agent":
+        take = get_take_actions(role="agent", spec=spec, rescale_points=rescale_points, reposition=reposition)
+        decode_one_hot = get_batch_decode_from_one_hot(d)
+    else:
+        raise ValueError(f"role must be either 'host' or 'agent'. Got {role}.")
+
+    def recurrent_fn(params, key, actions: torch.Tensor, observations: torch.Tensor):
+        role_fn_args, opponent_fn_args = params
+        batch_size = observations.shape[0]
+        prev_dones = get_dones(obs_preprocess(observations))
+        if role == "host":
+            # host acts (class ids -> masks), the agent answers, then the step happens
+            coords = batch_decode(actions, dtype)
+            opp = opponent_action_fn(make_agent_obs(observations, coords).to(dtype), *opponent_fn_args, key=key)
+            axis = torch.argmax(opp, dim=1)
+            next_observations = take(observations, coords, axis).to(dtype)
+            points_after = next_observations
+        else:
+            # the agent's axis finishes the move first; the host then answers on the new points
+            updated = take(observations, None, actions)
+            opp = opponent_action_fn(updated.to(dtype), *opponent_fn_args, key=key)
+            next_coords = decode_one_hot(opp, dtype)
+            next_observations = make_agent_obs(updated, next_coords).to(dtype)
+            points_after = updated
+        dones = get_dones(points_after.reshape(-1, m, d))
+        rewards = reward_fn(dones, prev_dones)
+        policy_prior, value_prior = role_fn(next_observations, *role_fn_args, key=key)
+        out = RecurrentFnOutput(reward=rewards,
+                                discount=torch.full((batch_size,), discount, dtype=dtype, device=observations.device),
+                                prior_logits=policy_prior, value=value_prior)
+        return out, next_observations
+
+    return recurrent_fn
+
+
+def get_unified_recurrent_fn(host_fn: Callable, agent_fn: Callable, reward_fn: Callable, spec: Tuple[int, int],
+                             discount: float = 0.99, dtype=torch.float32, rescale_points: bool = False,
+                             reposition: bool = False) -> Callable:
+    """recurrent_fn.py:126-199 -- one tree for both players: states are [B, m*d + d]; a host state has
+    a zero tail, an agent state carries the subset mask; the discount is negated; agent logits are
+    padded with -inf to the host's action count."""
+    m, d = spec
+    obs_preprocess, coords_preprocess = get_preprocess_fns("agent", spec)
+    batch_decode = get_batch_decode(d)
+    take = get_take_actions(role="host", spec=spec, rescale_points=rescale_points, reposition=reposition)
+    discount = -discount
+    extra = num_classes(d) - d
+
+    def recurrent_fn(params, key, actions: torch.Tensor, observations: torch.Tensor):
+        host_param, agent_param = params
+        batch_size = observations.shape[0]
+        obs, coord = obs_preprocess(observations), coords_preprocess(observations, None)
+        # all states of a batch are of the same kind (recurrent_fn.py:176-178)
+        is_host = bool(torch.isclose(coord, torch.zeros((), device=coord.device, dtype=coord.dtype)).all(dim=-1).any())
+        if is_host:
+            next_coord = batch_decode(actions, dtype)
+            next_obs = flatten(obs)
+        else:
+            next_coord = torch.zeros((batch_size, d), dtype=dtype, device=observations.device)
+            next_obs = take(obs.contiguous(), coord.contiguous(), actions)
+        next_state = torch.cat([next_obs.to(dtype), next_coord], dim=-1)
+        if is_host:  # the next node is an agent node
+            policy_prior, value_prior = agent_fn(next_state, *agent_param, key=key)
+            policy_prior = torch.nn.functional.pad(policy_prior, (0, extra), value=float("-inf"))
+        else:
+            policy_prior, value_prior = host_fn(next_state, *host_param, key=key)
+        prev_dones = get_dones(obs)
+        dones = get_dones(next_obs.reshape(-1, m, d))
+        rewards = reward_fn(dones, prev_dones)
+        out = RecurrentFnOutput(reward=rewards,
+                                discount=torch.full((batch_size,), discount, dtype=dtype, device=observations.device),
+                                prior_logits=policy_prior, value=value_prior)
+        return out, next_state
+
+    return recurrent_fn

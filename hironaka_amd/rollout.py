@@ -1,0 +1,127 @@
+"""Rollouts without a search: the counterparts of ``JAXTrainer.compute_rho``
+(hironaka/jax/jax_trainer.py:467-556) and of the shape of ``JAXTrainer.simulate``'s output
+(jax_trainer.py:247-320, 558-592).
+
+* ``compute_rho(host, agent, ...)`` -- policy-vs-policy games from freshly generated states; returns
+  (rho, details) with the reference's definitions: ``details[s]`` = #games that finished at exactly s
+  steps (the last bin collects what is left), ``rho = sum(details[1:]) / sum(s * details[s])``.
+  With the fixed policies of ``players.py`` given BY NAME the whole loop is ONE fused kernel launch
+  per batch (``hk_rollout``); with arbitrary callables it is the reference's step-by-step loop over
+  ``take_actions`` (one fused launch per step).
+* ``simulate_fixed_policies`` -- (obs, policy, value) tensors shaped like ``simulate``'s output
+  ``(B*T, obs_dim) / (B*T, A) / (B*T,)`` for fixed policies: observations before each step, one-hot
+  policy targets of the actions taken, and discounted-reward value targets (value of a finished game:
+  +-discount^k to the finishing step, the convention pinned by test/testJAXTrainer.py:91-389).
+  The Gumbel-MuZero search of the reference (third-party mctx) is NOT part of this build.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple, Union
+
+import torch
+
+from . import _abi as A
+from . import ops
+from .functional import flatten, generate_pts, get_dones, get_take_actions, make_agent_obs
+from .host_action_preprocess import get_batch_decode_from_one_hot, num_classes
+
+_HOSTS = {"random": A.HK_HOST_RANDOM, "all_coord": A.HK_HOST_ALL_COORD, "zeillinger": A.HK_HOST_ZEILLINGER}
+_AGENTS = {"random": A.HK_AGENT_RANDOM, "random_legal": A.HK_AGENT_RANDOM_LEGAL,
+           "choose_first": A.HK_AGENT_CHOOSE_FIRST, "choose_last": A.HK_AGENT_CHOOSE_LAST}
+
+
+def details_from_done_counts(done_count: torch.Tensor, total_games: int) -> List[int]:
+    """done_count[s] = #games finished after s steps (s = 0..L-1)  ->  the reference's `details`
+    histogram of length L (jax_trainer.py:501,525,540): details[s] = newly finished at step s for
+    s < L-1, details[L-1] = everything not finished after L-2 steps."""
+    dc = [int(v) for v in done_count.tolist()]
+    length = len(dc)
+    details = [0] * length
+    prev = 0
+    for s in range(length - 1):
+        details[s] = dc[s] - prev
+        prev = dc[s]
+    details[length - 1] = total_games - dc[length - 2] if length >= 2 else total_games
+    return details
+
+
+def rho_from_details(details: List[int]) -> float:
+    denom = sum(i * n for i, n in enumerate(details))
+    return sum(details[1:]) / denom if denom else float("nan")
+
+
+def compute_rho(host: Union[str, Callable], agent: Union[str, Callable], *, spec: Tuple[int, int],
+                batch_size: int, max_value: int, max_length: int, num_of_loops: int = 10,
+                reposition: bool = True, key: int = 0, dtype=torch.float32, device=None,
+                game_offset: int = 0, world_batch: Optional[int] = None) -> Tuple[float, List[int]]:
+    """jax_trainer.py:467-556.  `host` / `agent`: a name from players.py ("random", "all_coord",
+    "zeillinger" / "random", "random_legal", "choose_first", "choose_last") -> fused kernel; or
+    callables host(pts_flat, key=) -> one-hot [B, A], agent(agent_obs, key=) -> one-hot [B, d].
+    `game_offset` / `world_batch` place this process' shard inside a larger sharded batch."""
+    m, d = spec
+    stages = ops.make_stages(True, reposition, True, False)
+    fused = isinstance(host, str) and isinstance(agent, str)
+    world_batch = batch_size if world_batch is None else world_batch
+    totals = None
+    for loop in range(num_of_loops):
+        pts = generate_pts(key + loop, (batch_size, m, d), max_value, dtype, False, reposition,
+                           game_offset=game_offset, device=device)
+        if fused:
+            res = ops.rollout(pts, max_length - 1, key + loop, game_offset=game_offset, host_policy=_HOSTS[host],
+                              agent_policy=_AGENTS[agent], stages=stages)
+            counts = res["done_count"]
+        else:
+            take_action = get_take_actions("host", spec, rescale_points=False, reposition=reposition)
+            batch_decode = get_batch_decode_from_one_hot(d)
+            counts = torch.zeros(max_length, dtype=torch.int64, device=pts.device)
+            counts[0] = get_dones(pts).sum()
+            flat = flatten(pts)
+            for step in range(max_length - 1):
+                host_action = host(flat, key=key * 7919 + loop * 131 + 2 * step)
+                coords = batch_decode(host_action, dtype)
+                agent_obs = make_agent_obs(flat, coords)
+                axis = torch.argmax(agent(agent_obs, key=key * 7919 + loop * 131 + 2 * step + 1), dim=-1)
+                flat = take_action(flat, coords, axis)
+                counts[step + 1] = get_dones(flat.reshape(-1, m, d)).sum()
+        totals = counts.clone() if totals is None else totals + counts
+    details = details_from_done_counts(totals, batch_size * num_of_loops)
+    return rho_from_details(details), details
+
+
+def simulate_fixed_policies(key: int, role: str, *, spec: Tuple[int, int], batch_size: int, max_value: int,
+                            max_length_game: int, host: str = "random", agent: str = "random",
+                            reposition: bool = True, discount: float = 0.99, dtype=torch.float32,
+                            device=None, game_offset: int = 0):
+    """(obs, policy, value) with the shapes `JAXTrainer.simulate` returns for `role`:
+    host:  obs [B*T, m*d],     policy [B*T, 2^d-d-1] (one-hot of the class played)
+    agent: obs [B*T, m*d + d], policy [B*T, d]       (one-hot of the axis played)
+    value [B*T]: sign * discount^(steps until the game finishes) for games that finish inside the
+    rollout, sign/num_points for those that do not (jax/util.py:152-169,261-284); sign = +1 host, -1 agent."""
+    if role not in ("host", "agent"):
+        raise ValueError(f"role must be either host or agent. Got {role}.")
+    m, d = spec
+    T = max_length_game
+    pts = generate_pts(key, (batch_size, m, d), max_value, dtype, False, reposition, game_offset=game_offset,
+                       device=device)
+    stages = ops.make_stages(True, reposition, True, False)
+    res = ops.rollout(pts, T, key, game_offset=game_offset, host_policy=_HOSTS[host], agent_policy=_AGENTS[agent],
+                      stages=stages, record=("obs", "host_class", "axis", "done", "game_length"))
+    obs = res["obs"].reshape(T, batch_size, m * d)
+    sign = 1.0 if role == "host" else -1.0
+    if role == "host":
+        policy = torch.nn.functional.one_hot(res["host_class"].long(), num_classes(d)).to(dtype)
+    else:
+        coords = ops.decode_host_class(res["host_class"].reshape(-1), d, dtype).reshape(T, batch_size, d)
+        obs = torch.cat([obs, coords], dim=-1)
+        policy = torch.nn.functional.one_hot(res["axis"].long(), d).to(dtype)
+    length = res["game_length"].to(torch.int64)  # steps until done (0: at entry, -1: never)
+    t = torch.arange(T, device=obs.device).unsqueeze(1)
+    remaining = (length.unsqueeze(0) - 1 - t).clamp(min=0)  # moves left before the finishing one
+    finished = (length >= 0).unsqueeze(0)
+    npts = ops.get_num_points(pts).clamp(min=1).to(dtype)
+    tail = (T - 1 - t).to(dtype)
+    value = torch.where(finished, sign * discount ** remaining.to(dtype),
+                        sign / npts.unsqueeze(0) * discount ** tail)
+    # [T, B, .] -> [B*T, .] in the reference's (batch-major) order
+    to_bt = lambda x: x.transpose(0, 1).reshape(batch_size * T, *x.shape[2:])
+    return to_bt(obs), to_bt(policy), to_bt(value)

@@ -206,8 +206,11 @@ int hk_rollout(const hk_rollout_desc* desc, void* stream);
 uint64_t hk_rollout_workspace_bytes(const hk_rollout_desc* desc);
 
 /* ---- fixed host policy as its own operator: class id per game -------------------------- */
+/* flags: HK_SEM_JAX (default; all ordered pairs, isclose-degenerate pairs skipped, degenerate
+ * game -> class 0) or HK_SEM_LIST (host.py:70-95: pairs i<j of the available rows in row order,
+ * no isclose; a game with fewer than 2 available rows -> -1 = "no subset")                    */
 int hk_zeillinger(const void* points, int64_t stride, int32_t* class_out, int batch,
-                  int max_points, int dim, int dtype, void* stream);
+                  int max_points, int dim, int dtype, uint32_t flags, void* stream);
 
 /* ---- observation transform: [rescale] + rows sorted descending, last coordinate primary */
 int hk_get_features(const void* points_in, int64_t in_stride, void* features_out,

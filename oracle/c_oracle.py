@@ -167,11 +167,12 @@ def decode_host_class(cls: np.ndarray, dim: int, dtype=np.int32) -> np.ndarray:
     return out
 
 
-def zeillinger(points: np.ndarray) -> np.ndarray:
+def zeillinger(points: np.ndarray, sem: str = "jax") -> np.ndarray:
     points = np.ascontiguousarray(points)
     b, m, d = points.shape
     out = np.empty(b, dtype=np.int32)
-    _check(lib().hko_zeillinger(_ptr(points), m * d, _ptr(out), b, m, d, _hk_dtype(points)))
+    _check(lib().hko_zeillinger(_ptr(points), m * d, _ptr(out), b, m, d, _hk_dtype(points),
+                                A.SEMANTICS[sem]))
     return out
 
 

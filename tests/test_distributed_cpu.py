@@ -1,0 +1,69 @@
+"""World-size-2 tests of the multi-GPU path on CPU (gloo): shard arithmetic, the all-gather at the
+trainer boundary and the sharding invariance of the rollout (each rank computes its shard with
+game_offset = shard.start -- here through the oracle, standing in for the kernels that need a GPU --
+and the gathered result must equal the unsharded run)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from hironaka_amd import distributed as D
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, tmpdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import c_oracle as CO
+        CO.set_threads(1)
+        shard = D.shard_range(total)
+        assert D.world() == world and D.rank() == rank
+        m, d, T = 10, 3, 6
+        local = CO.generate_points(shard.size, m, d, 20, 42, game_offset=shard.start)
+        final, rec = CO.rollout(local, T, 7, game_offset=shard.start)
+        gathered = D.all_gather_games(torch.from_numpy(final), shard)
+        obs = D.all_gather_rollout((torch.from_numpy(rec["obs"][0]), torch.from_numpy(rec["axis"][0]),
+                                    torch.from_numpy(rec["reward"][0])), shard)
+        counts = D.all_reduce_counts(torch.from_numpy(rec["done_count"].astype(np.int64)))
+        if rank == 0:
+            np.savez(os.path.join(tmpdir, "out.npz"), final=gathered.numpy(), obs=obs[0].numpy(), axis=obs[1].numpy(),
+                     reward=obs[2].numpy(), counts=counts.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [64, 37])  # equal and ragged shards
+def test_two_rank_shards_equal_unsharded(tmp_path, total):
+    from oracle import c_oracle as CO
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "out.npz")
+    full = CO.generate_points(total, 10, 3, 20, 42)
+    final, rec = CO.rollout(full, 6, 7)
+    assert np.array_equal(got["final"], final)
+    assert np.array_equal(got["obs"], rec["obs"][0]) and np.array_equal(got["axis"], rec["axis"][0])
+    assert np.array_equal(got["reward"], rec["reward"][0])
+    assert np.array_equal(got["counts"], rec["done_count"].astype(np.int64))
+
+
+def test_shard_range_partitions():
+    for total in (0, 1, 7, 64, 65536, 524288 + 3):
+        for world in (1, 2, 3, 8):
+            shards = [D.shard_range(total, r, world) for r in range(world)]
+            assert shards[0].start == 0 and sum(s.size for s in shards) == total
+            for a, b in zip(shards, shards[1:]):
+                assert b.start == a.start + a.size and a.size - b.size in (0, 1)
+    assert D.world() == 1 and D.rank() == 0
+    x = torch.arange(6).reshape(3, 2)
+    assert D.all_gather_games(x) is x

@@ -290,6 +290,21 @@ def test_live_zeillinger_list(live_list):
     for b in range(len(pts)):
         rows = pts[b][pts[b][:, 0] >= 0]
         assert NO.zeillinger_list(rows) == tuple(coords[b]), b
+    # the C restatement of the list-semantics host (class id of the same subset; -1 below 2 points)
+    cls = CO.zeillinger(pts, sem="list")
+    want = np.zeros((len(pts), pts.shape[2]), dtype=np.int32)
+    for b in range(len(pts)):
+        want[b, coords[b]] = 1
+    assert np.array_equal(NO.decode_class(cls, pts.shape[2]), want)
+    lone = np.full((2, 4, 3), -1.0)
+    lone[1, 0] = [1, 2, 3]
+    assert CO.zeillinger(lone, sem="list").tolist() == [-1, -1]
+    for scale in (0, 1):  # and the host's choices inside the recorded config-1 games
+        states, masks = live_list[f"game_scale{scale}/states"], live_list[f"game_scale{scale}/masks"]
+        for t in range(len(masks)):
+            cls = CO.zeillinger(states[t], sem="list")
+            alive = cls >= 0
+            assert np.array_equal(NO.decode_class(cls[alive], 3), masks[t][alive]), (scale, t)
 
 
 # ------------------------------------------------------------------------------------------
