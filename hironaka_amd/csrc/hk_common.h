@@ -96,6 +96,25 @@ __host__ __device__ inline U4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, 
   return U4{c0, c1, c2, c3};
 }
 
+// The two 32-bit words (host draw, agent draw) of policy step `step` of game `gg` (DESIGN.md
+// "Randomness"): Philox block (gg_lo, gg_hi, step >> 1, kStreamPolicy) serves two consecutive
+// steps -- words (x, y) for the even one, (z, w) for the odd one.
+struct PolicyCache {
+  U4 r;
+  uint32_t block = 0xFFFFFFFFu;  // wave-uniform: which block `r` holds
+};
+
+__host__ __device__ inline void policy_words(uint64_t gg, uint32_t step, uint64_t seed, PolicyCache& cache,
+                                             uint32_t& host_word, uint32_t& agent_word) {
+  const uint32_t block = step >> 1;
+  if (cache.block != block) {
+    cache.r = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), block, kStreamPolicy, seed);
+    cache.block = block;
+  }
+  host_word = (step & 1u) ? cache.r.z : cache.r.x;
+  agent_word = (step & 1u) ? cache.r.w : cache.r.y;
+}
+
 // floor(r * n / 2^32): 32-bit word -> [0, n)
 __host__ __device__ inline uint32_t mulhi32(uint32_t r, uint32_t n) {
   return (uint32_t)(((uint64_t)r * n) >> 32);

@@ -37,6 +37,7 @@
 
 #include <type_traits>
 
+#include "hk_fast_rows.h"
 #include "hk_generic_kernel.h"
 
 namespace hk {
@@ -47,6 +48,10 @@ struct FastGeom {
   static constexpr int W = (N % 4 == 0) ? 4 : ((N % 2 == 0) ? 2 : 1);
   static constexpr int Q = N / W;                     // W-chunks per game
   static constexpr int S = (Q % 2 == 1) ? N : N + W;  // LDS stride in floats, S/W odd
+  // register capacity: live rows a lane can hold.  Beyond 32 rows the state would not fit the VGPR
+  // budget at a useful occupancy; a wave whose widest game has more live rows than C runs the exact
+  // generic routines on its LDS image instead (Newton-reduced states of 50 slots hold ~12 rows).
+  static constexpr int C = (M <= 32) ? M : 32;
 };
 
 template <int W> struct VecOf;
@@ -54,20 +59,13 @@ template <> struct VecOf<4> { using type = float4; };
 template <> struct VecOf<2> { using type = float2; };
 template <> struct VecOf<1> { using type = float; };
 
-template <int M>
-using MaskT = typename std::conditional<(M <= 32), uint32_t, unsigned long long>::type;
-
-__device__ inline int mask_pop(uint32_t m) { return __popc(m); }
-__device__ inline int mask_pop(unsigned long long m) { return __popcll(m); }
-__device__ inline int mask_first(uint32_t m) { return __ffs(m) - 1; }
-__device__ inline int mask_first(unsigned long long m) { return __ffsll(m) - 1; }
-
 // wave-wide maximum of a small int in [0, hi], returned in an SGPR: a downward search with one
 // ballot per candidate (scalar compares only) instead of a 6-deep chain of cross-lane shuffles whose
 // LDS-crossbar latency a lone wave per SIMD cannot hide.  From a previous maximum it ends after a
 // step or two.
 __device__ inline int wave_max(int v, int hi) {
   int m = hi;
+#pragma nounroll
   while (m > 0 && !__any(v >= m)) --m;
   return m;
 }
@@ -137,44 +135,6 @@ __device__ inline void scan_image(const float* mine, float fill, MaskT<M>& live,
   }
 }
 
-// rows of the set bits of `mask`, ascending, into q[0..n); q[n..nmax) := +inf
-template <int M, int D>
-__device__ inline void gather_rows(float (&q)[M * D], const float* mine, MaskT<M> mask, int nmax) {
-#pragma unroll
-  for (int r = 0; r < M; ++r) {
-    if (r >= nmax) break;
-    const bool has = mask != 0;
-    const int s = has ? mask_first(mask) : 0;
-    mask &= mask - 1;
-    const float* row = mine + s * D;
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-      const float v = row[k];
-      q[r * D + k] = has ? v : INFINITY;
-    }
-  }
-}
-
-// live rows of q back to their slots; returns the mask of the slots still alive
-template <int M, int D>
-__device__ inline MaskT<M> scatter_rows(const float (&q)[M * D], float* mine, MaskT<M> mask, int nmax) {
-  MaskT<M> alive = 0;
-#pragma unroll
-  for (int r = 0; r < M; ++r) {
-    if (r >= nmax) break;
-    const bool has = mask != 0;
-    const int s = has ? mask_first(mask) : 0;
-    mask &= mask - 1;
-    if (has && q[r * D] < INFINITY) {
-      alive |= (MaskT<M>)1 << s;
-      float* row = mine + s * D;
-#pragma unroll
-      for (int k = 0; k < D; ++k) row[k] = q[r * D + k];
-    }
-  }
-  return alive;
-}
-
 template <int M, int D>
 __device__ inline void fill_image(float* mine, float pad) {
   using G = FastGeom<M, D>;
@@ -185,132 +145,6 @@ __device__ inline void fill_image(float* mine, float pad) {
   for (int w = 0; w < G::W; ++w) f[w] = pad;
 #pragma unroll
   for (int c = 0; c < G::Q; ++c) *reinterpret_cast<V*>(mine + c * G::W) = v;
-}
-
-template <int M, int D>
-__device__ inline int count_live(const float (&q)[M * D], int nmax) {
-  int n = 0;
-#pragma unroll
-  for (int r = 0; r < M; ++r) {
-    if (r >= nmax) break;
-    n += (q[r * D] < INFINITY) ? 1 : 0;
-  }
-  return n;
-}
-
-// ---- the stages on the gathered rows ------------------------------------------------------------
-// _jax_ops.py:76-90 / _torch_ops.py:46-110
-template <int M, int D>
-__device__ inline void c_shift(float (&q)[M * D], int nmax, const float (&c)[D], int axis, int np,
-                               unsigned flags) {
-  bool apply = true;
-  if (flags & HK_FLAG_AXIS_NOOP_IF_INVALID) {
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-      const float onehot = (k == axis) ? 1.0f : 0.0f;
-      if (!(onehot - c[k] <= 0.0f)) apply = false;
-    }
-  }
-  if ((flags & HK_FLAG_IGNORE_ENDED) && np < 2) apply = false;
-  bool isax[D];
-#pragma unroll
-  for (int k = 0; k < D; ++k) isax[k] = apply && (k == axis);
-#pragma unroll
-  for (int r = 0; r < M; ++r) {
-    if (r >= nmax) break;
-    float s = 0.0f;
-#pragma unroll
-    for (int k = 0; k < D; ++k) s = s + q[r * D + k] * c[k];  // order 0..D-1, no contraction
-    const bool live = q[r * D] < INFINITY;                   // holes would give inf*0 = NaN
-#pragma unroll
-    for (int k = 0; k < D; ++k) q[r * D + k] = (live && isax[k]) ? s : q[r * D + k];
-  }
-}
-
-// _jax_ops.py:114-123 / _torch_ops.py:113-133 (padding rows are not in q)
-template <int M, int D>
-__device__ inline void c_reposition(float (&q)[M * D], int nmax, unsigned flags) {
-  const bool jax_sem = (flags & HK_SEM_MASK) == HK_SEM_JAX;
-#pragma unroll
-  for (int k = 0; k < D; ++k) {
-    float mn = INFINITY;
-#pragma unroll
-    for (int r = 0; r < M; ++r) {
-      if (r >= nmax) break;
-      mn = fminf(mn, q[r * D + k]);
-    }
-    // JAX leaves a column whose minimum is <= 0 untouched: subtracting 0 is the same thing
-    const float sub = (mn < INFINITY && (!jax_sem || mn > 0.0f)) ? mn : 0.0f;
-#pragma unroll
-    for (int r = 0; r < M; ++r) {
-      if (r >= nmax) break;
-      q[r * D + k] = q[r * D + k] - sub;  // inf - sub = inf: holes stay holes
-    }
-  }
-}
-
-template <int D>
-__device__ inline void diff_extrema(const float* a, const float* b, float& t, float& u) {
-  const float d0 = a[0] - b[0];
-  t = d0;
-  u = d0;
-#pragma unroll
-  for (int k = 1; k < D; ++k) {
-    const float dk = a[k] - b[k];
-    t = fmaxf(t, dk);
-    u = fminf(u, dk);
-  }
-}
-
-// _jax_ops.py:15-73: removed rows become holes
-template <int M, int D>
-__device__ inline void c_newton(float (&q)[M * D], int nmax) {
-  float acc[M];
-#pragma unroll
-  for (int r = 0; r < M; ++r) acc[r] = INFINITY;
-#pragma unroll
-  for (int i = 0; i < M - 1; ++i) {
-    if (i + 1 >= nmax) break;
-#pragma unroll
-    for (int j = i + 1; j < M; ++j) {
-      if (j >= nmax) break;
-      float t, u;
-      diff_extrema<D>(&q[i * D], &q[j * D], t, u);
-      acc[j] = fminf(acc[j], t);
-      acc[i] = fminf(acc[i], (t > 0.0f) ? -u : 1.0f);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < M; ++r) {
-    if (r >= nmax) break;
-    const bool removed = acc[r] <= 0.0f;
-#pragma unroll
-    for (int k = 0; k < D; ++k) q[r * D + k] = removed ? INFINITY : q[r * D + k];
-  }
-}
-
-// _jax_ops.py:93-111 / _torch_ops.py:136-146 on the live rows (the maximum over a game that has a
-// live row is attained on a live row; a game without one is all padding and does not change)
-template <int M, int D>
-__device__ inline void c_rescale(float (&q)[M * D], int nmax, unsigned flags) {
-  const bool jax_sem = (flags & HK_SEM_MASK) == HK_SEM_JAX;
-  float mx = -1.0f;
-#pragma unroll
-  for (int r = 0; r < M; ++r) {
-    if (r >= nmax) break;
-    const bool live = q[r * D] < INFINITY;
-#pragma unroll
-    for (int k = 0; k < D; ++k) mx = fmaxf(mx, live ? q[r * D + k] : -1.0f);
-  }
-  const bool skip = jax_sem ? (mx <= 1e-8f) : (mx < 0.0f);
-  const float div = (skip || mx == 0.0f) ? 1.0f : mx;
-#pragma unroll
-  for (int r = 0; r < M; ++r) {
-    if (r >= nmax) break;
-    const bool live = q[r * D] < INFINITY;
-#pragma unroll
-    for (int k = 0; k < D; ++k) q[r * D + k] = live ? q[r * D + k] / div : INFINITY;
-  }
 }
 
 template <int D>
@@ -336,17 +170,19 @@ __device__ inline void fast_load_coords(const Params& prm, int64_t g, int m, flo
 }
 
 // random / fixed policies of jax/players.py (not Zeillinger: that one runs on the generic kernel)
+// `cache` holds the Philox block of steps {2b, 2b+1}: the fused loop calls Philox every other step.
 template <int D>
-__device__ inline void fast_policy(const Params& prm, uint64_t gg, uint32_t step, int& cls, int& axis,
-                                   uint32_t& mask) {
+__device__ inline void fast_policy(const Params& prm, uint64_t gg, uint32_t step, PolicyCache& cache,
+                                   int& cls, int& axis, uint32_t& mask) {
   constexpr uint32_t ncls = (1u << D) - (uint32_t)D - 1u;
-  const U4 r = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), step, kStreamPolicy, prm.seed);
-  cls = (prm.host_policy == HK_HOST_RANDOM) ? (int)mulhi32(r.x, ncls) : (int)ncls - 1;
+  uint32_t ra, rb;
+  policy_words(gg, step, prm.seed, cache, ra, rb);
+  cls = (prm.host_policy == HK_HOST_RANDOM) ? (int)mulhi32(ra, ncls) : (int)ncls - 1;
   mask = decode_class(cls, D);
   if (prm.agent_policy == HK_AGENT_RANDOM) {
-    axis = (int)mulhi32(r.y, (uint32_t)D);
+    axis = (int)mulhi32(rb, (uint32_t)D);
   } else if (prm.agent_policy == HK_AGENT_RANDOM_LEGAL) {
-    const int pick = (int)mulhi32(r.y, (uint32_t)__popc(mask));
+    const int pick = (int)mulhi32(rb, (uint32_t)__popc(mask));
     int seen = 0;
     axis = 0;
 #pragma unroll
@@ -381,6 +217,7 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
   const unsigned stages = (MODE == kModeGenerate) ? (prm.stages & ~HK_STAGE_SHIFT) : prm.stages;
   const float fill = ((flags & HK_SEM_MASK) == HK_SEM_TORCH) ? pad : -1.0f;
   const int nsteps = (MODE == kModeRollout) ? prm.steps : 1;
+  PolicyCache pcache;
 
   // step mode: issue the action loads first so their latency hides under the slab copy
   float c[D];
@@ -416,12 +253,14 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
     gmask = 0;
     ok = true;
   }
-  const bool exact = (fill == pad) && __all(ok);
+  int np = mask_pop(gmask);
+  int nmax = wave_max(np, M);
+  const bool exact = (fill == pad) && __all(ok) && nmax <= G::C;
 
   if (!exact) {
     // ---- slow path (whole wave): the exact generic routines on the image ------------------------
     float* cs = cbuf + lane * D;
-    int np = active ? num_points<float>(mine, M, D) : 2;
+    np = active ? num_points<float>(mine, M, D) : 2;
     int length = (np < 2) ? 0 : -1;
     if (MODE == kModeRollout && prm.count_ws) {
       const unsigned long long b0 = __ballot(active && np < 2);
@@ -437,7 +276,7 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
           __syncthreads();
         }
         uint32_t mask;
-        fast_policy<D>(prm, gg, prm.step_offset + (uint32_t)t, cls, axis, mask);
+        fast_policy<D>(prm, gg, prm.step_offset + (uint32_t)t, pcache, cls, axis, mask);
         for (int k = 0; k < prm.d; ++k) cs[k] = (float)((mask >> k) & 1u);
       } else if (MODE == kModeStep && (stages & HK_STAGE_SHIFT) && active) {
         load_coords<float>(prm, g, cs);
@@ -474,10 +313,8 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
   }
 
   // ---- 3. gather the live rows ------------------------------------------------------------------------
-  float q[M * D];
-  int np = mask_pop(gmask);
-  int nmax = wave_max(np, M);
-  gather_rows<M, D>(q, mine, gmask, nmax);
+  float q[G::C * D];
+  gather_rows<M, G::C, D>(q, mine, gmask, nmax);
   if (!active) np = 2;  // never "done", never counted
   int length = (np < 2) ? 0 : -1;
   if (MODE == kModeRollout && prm.count_ws) {
@@ -492,13 +329,13 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
       if (prm.obs_out) {  // state before the step: rebuild the image, store it coalesced
         __syncthreads();
         fill_image<M, D>(mine, pad);
-        scatter_rows<M, D>(q, mine, gmask, nmax);
+        scatter_rows<M, G::C, D>(q, mine, gmask, nmax);
         __syncthreads();
         fast_store_slab<M, D>(lds, (float*)prm.obs_out + (int64_t)t * prm.batch * G::N, (int64_t)G::N,
                               g0, ngames, lane);
       }
       uint32_t mask;
-      fast_policy<D>(prm, gg, prm.step_offset + (uint32_t)t, cls, axis, mask);
+      fast_policy<D>(prm, gg, prm.step_offset + (uint32_t)t, pcache, cls, axis, mask);
 #pragma unroll
       for (int k = 0; k < D; ++k) c[k] = (float)((mask >> k) & 1u);
     } else if (MODE == kModeStep) {
@@ -506,12 +343,12 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
     }
     const bool prev_done = np < 2;
 
-    if (stages & HK_STAGE_SHIFT) c_shift<M, D>(q, nmax, c, axis, np, flags);
-    if (stages & HK_STAGE_REPOSITION) c_reposition<M, D>(q, nmax, flags);
-    if (stages & HK_STAGE_NEWTON) c_newton<M, D>(q, nmax);
-    if (stages & HK_STAGE_RESCALE) c_rescale<M, D>(q, nmax, flags);
+    if (stages & HK_STAGE_SHIFT) c_shift<G::C, D>(q, nmax, c, axis, np, flags);
+    if (stages & HK_STAGE_REPOSITION) c_reposition<G::C, D>(q, nmax, flags);
+    if (stages & HK_STAGE_NEWTON) c_newton<G::C, D>(q, nmax);
+    if (stages & HK_STAGE_RESCALE) c_rescale<G::C, D>(q, nmax, flags);
 
-    np = active ? count_live<M, D>(q, nmax) : 2;
+    np = active ? count_live<G::C, D>(q, nmax) : 2;
     const bool done = np < 2;
     if (done && length < 0) length = t + 1;
     if (MODE == kModeRollout) {
@@ -529,9 +366,9 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
       // re-gather when the widest game of the wave got narrower (removed rows are holes until then)
       // (one ballot per step; the cross-lane maximum only when some game still fills all nmax rows)
       if (t + 1 < nsteps && !__any(active && np >= nmax)) {
-        gmask = scatter_rows<M, D>(q, mine, gmask, nmax);
+        gmask = scatter_rows<M, G::C, D>(q, mine, gmask, nmax);
         nmax = wave_max(active ? np : 0, nmax - 1);
-        gather_rows<M, D>(q, mine, gmask, nmax);
+        gather_rows<M, G::C, D>(q, mine, gmask, nmax);
       }
     } else if (MODE == kModeStep && active) {
       if (prm.done_out) prm.done_out[g] = done;
@@ -545,7 +382,7 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
   // ---- 5. publish: pad everywhere, live rows back in their slots ---------------------------------
   __syncthreads();
   fill_image<M, D>(mine, pad);
-  scatter_rows<M, D>(q, mine, gmask, nmax);
+  scatter_rows<M, G::C, D>(q, mine, gmask, nmax);
   __syncthreads();
   fast_store_slab<M, D>(lds, (float*)prm.out, prm.out_stride, g0, ngames, lane);
 }

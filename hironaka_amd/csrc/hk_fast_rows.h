@@ -1,0 +1,220 @@
+// The stages of the Hironaka step on the live rows a lane holds in registers (see hk_fast_kernel.h).
+//
+// q[C*D]: up to C rows with COMPILE-TIME indices; rows [n, nmax) of a lane are +inf holes; nmax is
+// wave-uniform.  Every row loop must (a) be fully unrolled -- a rolled loop would index q dynamically
+// and push it into scratch memory -- and (b) leave early on `r >= nmax` with a scalar branch.  LLVM only
+// unrolls such "upper-bound" loops up to 8 iterations by default, so the unrolling is done by
+// construction: `unrolled_while<0, C>(f)` calls f(integral_constant<r>) for r = 0, 1, ... and stops at
+// the first `false`, as nested ifs the optimiser cannot re-roll.
+#pragma once
+
+#include <type_traits>
+
+#include "hk_common.h"
+
+namespace hk {
+
+template <int I, int N>
+struct UnrolledWhile {
+  template <typename F>
+  static __device__ __forceinline__ void run(F&& f) {
+    if (f(std::integral_constant<int, I>{})) UnrolledWhile<I + 1, N>::run(f);
+  }
+};
+template <int N>
+struct UnrolledWhile<N, N> {
+  template <typename F>
+  static __device__ __forceinline__ void run(F&&) {}
+};
+template <int I0, int N, typename F>
+__device__ __forceinline__ void unrolled_while(F&& f) {
+  UnrolledWhile<(I0 < N ? I0 : N), N>::run(f);
+}
+
+template <int M>
+using MaskT = typename std::conditional<(M <= 32), uint32_t, unsigned long long>::type;
+
+__device__ inline int mask_pop(uint32_t m) { return __popc(m); }
+__device__ inline int mask_pop(unsigned long long m) { return __popcll(m); }
+__device__ inline int mask_first(uint32_t m) { return __ffs(m) - 1; }
+__device__ inline int mask_first(unsigned long long m) { return __ffsll(m) - 1; }
+
+// rows of the set bits of `mask`, ascending, into q[0..n); q[n..nmax) := +inf
+template <int M, int C, int D>
+__device__ __forceinline__ void gather_rows(float (&q)[C * D], const float* mine, MaskT<M> mask, int nmax) {
+  unrolled_while<0, C>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    if (r >= nmax) return false;
+    const bool has = mask != 0;
+    const int s = has ? mask_first(mask) : 0;
+    mask &= mask - 1;
+    const float* row = mine + s * D;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const float v = row[k];
+      q[r * D + k] = has ? v : INFINITY;
+    }
+    return true;
+  });
+}
+
+// live rows of q back to their slots; returns the mask of the slots still alive
+template <int M, int C, int D>
+__device__ __forceinline__ MaskT<M> scatter_rows(const float (&q)[C * D], float* mine, MaskT<M> mask, int nmax) {
+  MaskT<M> alive = 0;
+  unrolled_while<0, C>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    if (r >= nmax) return false;
+    const bool has = mask != 0;
+    const int s = has ? mask_first(mask) : 0;
+    mask &= mask - 1;
+    if (has && q[r * D] < INFINITY) {
+      alive |= (MaskT<M>)1 << s;
+      float* row = mine + s * D;
+#pragma unroll
+      for (int k = 0; k < D; ++k) row[k] = q[r * D + k];
+    }
+    return true;
+  });
+  return alive;
+}
+
+template <int C, int D>
+__device__ __forceinline__ int count_live(const float (&q)[C * D], int nmax) {
+  int n = 0;
+  unrolled_while<0, C>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    if (r >= nmax) return false;
+    n += (q[r * D] < INFINITY) ? 1 : 0;
+    return true;
+  });
+  return n;
+}
+
+// _jax_ops.py:76-90 / _torch_ops.py:46-110
+template <int C, int D>
+__device__ __forceinline__ void c_shift(float (&q)[C * D], int nmax, const float (&c)[D], int axis, int np,
+                                        unsigned flags) {
+  bool apply = true;
+  if (flags & HK_FLAG_AXIS_NOOP_IF_INVALID) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const float onehot = (k == axis) ? 1.0f : 0.0f;
+      if (!(onehot - c[k] <= 0.0f)) apply = false;
+    }
+  }
+  if ((flags & HK_FLAG_IGNORE_ENDED) && np < 2) apply = false;
+  bool isax[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) isax[k] = apply && (k == axis);
+  unrolled_while<0, C>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    if (r >= nmax) return false;
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < D; ++k) s = s + q[r * D + k] * c[k];  // order 0..D-1, no contraction
+    const bool live = q[r * D] < INFINITY;                   // holes would give inf*0 = NaN
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[r * D + k] = (live && isax[k]) ? s : q[r * D + k];
+    return true;
+  });
+}
+
+// _jax_ops.py:114-123 / _torch_ops.py:113-133 (padding rows are not in q)
+template <int C, int D>
+__device__ __forceinline__ void c_reposition(float (&q)[C * D], int nmax, unsigned flags) {
+  const bool jax_sem = (flags & HK_SEM_MASK) == HK_SEM_JAX;
+  float mn[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) mn[k] = INFINITY;
+  unrolled_while<0, C>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    if (r >= nmax) return false;
+#pragma unroll
+    for (int k = 0; k < D; ++k) mn[k] = fminf(mn[k], q[r * D + k]);
+    return true;
+  });
+  float sub[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k)  // JAX leaves a column whose minimum is <= 0 untouched: subtract 0
+    sub[k] = (mn[k] < INFINITY && (!jax_sem || mn[k] > 0.0f)) ? mn[k] : 0.0f;
+  unrolled_while<0, C>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    if (r >= nmax) return false;
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[r * D + k] = q[r * D + k] - sub[k];  // inf - sub = inf: holes stay
+    return true;
+  });
+}
+
+template <int D>
+__device__ __forceinline__ void diff_extrema(const float* a, const float* b, float& t, float& u) {
+  const float d0 = a[0] - b[0];
+  t = d0;
+  u = d0;
+#pragma unroll
+  for (int k = 1; k < D; ++k) {
+    const float dk = a[k] - b[k];
+    t = fmaxf(t, dk);
+    u = fminf(u, dk);
+  }
+}
+
+// _jax_ops.py:15-73: removed rows become holes.  Pair i<j:  t = max_k(q_i-q_j), u = min_k(q_i-q_j);
+// j removed iff t <= 0 (ties go to the lower index), i removed iff u >= 0 and t > 0.
+template <int C, int D>
+__device__ __forceinline__ void c_newton(float (&q)[C * D], int nmax) {
+  float acc[C];
+#pragma unroll
+  for (int r = 0; r < C; ++r) acc[r] = INFINITY;
+  unrolled_while<0, C - 1>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    if (i + 1 >= nmax) return false;
+    unrolled_while<i + 1, C>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if (j >= nmax) return false;
+      float t, u;
+      diff_extrema<D>(&q[i * D], &q[j * D], t, u);
+      acc[j] = fminf(acc[j], t);
+      acc[i] = fminf(acc[i], (t > 0.0f) ? -u : 1.0f);
+      return true;
+    });
+    return true;
+  });
+  unrolled_while<0, C>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    if (r >= nmax) return false;
+    const bool removed = acc[r] <= 0.0f;
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[r * D + k] = removed ? INFINITY : q[r * D + k];
+    return true;
+  });
+}
+
+// _jax_ops.py:93-111 / _torch_ops.py:136-146 on the live rows (the maximum over a game that has a
+// live row is attained on a live row; a game without one is all padding and does not change)
+template <int C, int D>
+__device__ __forceinline__ void c_rescale(float (&q)[C * D], int nmax, unsigned flags) {
+  const bool jax_sem = (flags & HK_SEM_MASK) == HK_SEM_JAX;
+  float mx = -1.0f;
+  unrolled_while<0, C>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    if (r >= nmax) return false;
+    const bool live = q[r * D] < INFINITY;
+#pragma unroll
+    for (int k = 0; k < D; ++k) mx = fmaxf(mx, live ? q[r * D + k] : -1.0f);
+    return true;
+  });
+  const bool skip = jax_sem ? (mx <= 1e-8f) : (mx < 0.0f);
+  const float div = (skip || mx == 0.0f) ? 1.0f : mx;
+  unrolled_while<0, C>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    if (r >= nmax) return false;
+    const bool live = q[r * D] < INFINITY;
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[r * D + k] = live ? q[r * D + k] / div : INFINITY;
+    return true;
+  });
+}
+
+}  // namespace hk

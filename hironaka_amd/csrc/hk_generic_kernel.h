@@ -80,15 +80,17 @@ __device__ inline void choose_actions(const T* p, const Params& prm, uint64_t gg
                                       int& cls, int& axis, uint32_t& mask) {
   const int d = prm.d;
   const uint32_t ncls = (1u << d) - (uint32_t)d - 1u;
-  const U4 r = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), step, kStreamPolicy, prm.seed);
-  if (prm.host_policy == HK_HOST_RANDOM) cls = (int)mulhi32(r.x, ncls);
+  PolicyCache cache;
+  uint32_t ra, rb;
+  policy_words(gg, step, prm.seed, cache, ra, rb);
+  if (prm.host_policy == HK_HOST_RANDOM) cls = (int)mulhi32(ra, ncls);
   else if (prm.host_policy == HK_HOST_ALL_COORD) cls = (int)ncls - 1;
   else cls = zeillinger_game(p, prm.m, d);
   mask = decode_class(cls, d);
   if (prm.agent_policy == HK_AGENT_RANDOM) {
-    axis = (int)mulhi32(r.y, (uint32_t)d);
+    axis = (int)mulhi32(rb, (uint32_t)d);
   } else if (prm.agent_policy == HK_AGENT_RANDOM_LEGAL) {
-    const int pick = (int)mulhi32(r.y, (uint32_t)__popc(mask));
+    const int pick = (int)mulhi32(rb, (uint32_t)__popc(mask));
     int seen = 0;
     axis = 0;
     for (int k = 0; k < d; ++k)
