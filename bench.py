@@ -56,6 +56,22 @@ def algorithmic_bytes_per_step(m: int, d: int) -> int:
     return 2 * m * d * 4 + 4 * d + 4 + 4 + 1
 
 
+def measured_traffic(key: str):
+    """HBM bytes per launch from the committed rocprofv3 PMC profile (profiles/r*_hbm_traffic.json,
+    written by scripts/summarise_profile.py; FETCH_SIZE x2 on gfx950 + WRITE_SIZE), newest round first.
+    PMC counters cannot be collected from inside the benchmark process, hence the committed file."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                data = json.load(f)
+            if data.get("batch") == BATCH and key in data:
+                return data[key], os.path.relpath(path, ROOT)
+        except (OSError, ValueError):
+            continue
+    return None, None
+
+
 def capture(fn):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
@@ -204,6 +220,11 @@ def main():
         launch_s = (region_ms / 1e3) / max(1, launches)
         steps_per_launch = K / max(1, launches)
         achieved = b * bytes_step * steps_per_launch / launch_s / 1e9
+        traffic, traffic_src = (None, None)
+        if b == BATCH and rem == 0:
+            traffic, traffic_src = measured_traffic("rollout_T20_bytes_per_launch")
+        if single is not None and b == BATCH:
+            single["traffic"], _ = measured_traffic("single_step_bytes_per_launch")
         out = {
             "metric": "env-steps/sec at dim=3, max_pts=20, batch=65536; 1/2/4/8 GPUs",
             "value": world * b * K / elapsed,
@@ -232,7 +253,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": int(b * bytes_step * steps_per_launch),
                 "mean_launch_us": launch_s * 1e6,
                 "note": "algorithmic = 501 B/env-step (SURVEY 8d) x games x steps; the fused kernel keeps the "
