@@ -2,6 +2,7 @@
 // and launch.  No allocation, no synchronisation, no exceptions; every entry point returns a
 // status code.  gfx950 only.
 #include "hk_fast_kernel.h"
+#include "hk_mid_kernel.h"
 #include "hk_generic_kernel.h"
 
 using namespace hk;
@@ -56,9 +57,15 @@ int launch_generic(Params& prm, int dtype, hipStream_t stream) {
   return dtype == HK_F32 ? launch_generic_t<float>(prm, stream) : launch_generic_t<double>(prm, stream);
 }
 
+// kernel selection: register-resident specialisation -> LDS-rows kernel (f32, dim 2..6, <= 64 rows)
+// -> generic kernel (anything else: f64, list semantics, sorted output, Zeillinger, feature sort)
 int launch(Params& prm, int dtype, hipStream_t stream) {
   if (prm.batch == 0) return HK_OK;
   if (fast_supported(prm, dtype)) return launch_fast(prm, stream);
+  if (mid_supported(prm, dtype)) {
+    const int st = launch_mid(prm, stream);
+    if (st != HK_ERR_UNSUPPORTED) return st;
+  }
   return launch_generic(prm, dtype, stream);
 }
 
@@ -66,6 +73,8 @@ int launch(Params& prm, int dtype, hipStream_t stream) {
 int64_t planned_grid(Params prm, int dtype) {
   if (prm.batch == 0) return 0;
   if (fast_supported(prm, dtype)) return ((int64_t)prm.batch + kWave - 1) / kWave;
+  if (mid_supported(prm, dtype) && plan_mid(prm) == HK_OK)
+    return ((int64_t)prm.batch + prm.games_per_block - 1) / prm.games_per_block;
   if (plan_generic(prm, dtype) != HK_OK) return 0;
   return ((int64_t)prm.batch + prm.games_per_block - 1) / prm.games_per_block;
 }

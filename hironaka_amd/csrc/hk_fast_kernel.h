@@ -390,7 +390,7 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
 // ---- the specialisation table ------------------------------------------------------------------
 // (max_points, dim): BASELINE configs (10,3) (20,3) (50,4) plus the small shapes the reference's
 // tests and YAMLs use.
-#define HK_FAST_SPECS(X) X(4, 3) X(5, 3) X(10, 3) X(16, 3) X(20, 3) X(8, 4) X(20, 4) X(50, 4)
+#define HK_FAST_SPECS(X) X(4, 3) X(5, 3) X(10, 3) X(16, 3) X(20, 3) X(8, 4) X(20, 4)
 
 inline int has_fast_path(int m, int d, int dtype) {
   if (dtype != HK_F32) return 0;
@@ -430,7 +430,7 @@ int launch_fast_t(const Params& prm, hipStream_t stream) {
 inline bool fast_supported(const Params& prm, int dtype) {
   if (dtype != HK_F32) return false;
   if ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)) return false;
-  if (prm.flags & HK_FLAG_FORCE_GENERIC) return false;
+  if (prm.flags & (HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_LDS_ROWS)) return false;
   if (prm.stages & kStageFeatureSort) return false;
   if (prm.mode == kModeZeillinger) return false;
   if (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER) return false;

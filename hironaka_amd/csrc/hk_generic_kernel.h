@@ -18,38 +18,53 @@
 namespace hk {
 
 // cooperative, coalesced HBM -> LDS copy of `ngames` records of `n` elements
-template <typename T>
-__device__ inline void load_slab(T* lds, const T* in, int64_t in_stride, int n, int S, int64_t g0,
-                                 int ngames, int lane) {
+// (rolled loop, n is a run-time value: batched by hand so that kSlabBatch independent requests per lane
+// are in flight before the first dependent access -- one per iteration would expose a full HBM latency)
+constexpr int kSlabBatch = 8;
+
+template <typename T, bool TO_LDS>
+__device__ inline void copy_slab(T* lds, T* glob, int64_t gstride, int n, int S, int64_t g0, int ngames,
+                                 int lane) {
   int g = lane / n, e = lane % n;
   const int dg = kWave / n, de = kWave % n;
   const int total = ngames * n;
-  for (int c = lane; c < total; c += kWave) {
-    lds[g * S + e] = in[(g0 + g) * in_stride + e];
-    g += dg;
-    e += de;
-    if (e >= n) {
-      e -= n;
-      ++g;
+  for (int c0 = lane; c0 < total; c0 += kWave * kSlabBatch) {
+    T v[kSlabBatch];
+    int lo[kSlabBatch];
+    int64_t go[kSlabBatch];
+#pragma unroll
+    for (int u = 0; u < kSlabBatch; ++u) {
+      lo[u] = g * S + e;
+      go[u] = (g0 + g) * gstride + e;
+      g += dg;
+      e += de;
+      if (e >= n) {
+        e -= n;
+        ++g;
+      }
     }
+#pragma unroll
+    for (int u = 0; u < kSlabBatch; ++u)
+      if (c0 + u * kWave < total) v[u] = TO_LDS ? glob[go[u]] : lds[lo[u]];
+#pragma unroll
+    for (int u = 0; u < kSlabBatch; ++u)
+      if (c0 + u * kWave < total) {
+        if (TO_LDS) lds[lo[u]] = v[u];
+        else glob[go[u]] = v[u];
+      }
   }
+}
+
+template <typename T>
+__device__ inline void load_slab(T* lds, const T* in, int64_t in_stride, int n, int S, int64_t g0,
+                                 int ngames, int lane) {
+  copy_slab<T, true>(lds, const_cast<T*>(in), in_stride, n, S, g0, ngames, lane);
 }
 
 template <typename T>
 __device__ inline void store_slab(const T* lds, T* out, int64_t out_stride, int n, int S,
                                   int64_t g0, int ngames, int lane) {
-  int g = lane / n, e = lane % n;
-  const int dg = kWave / n, de = kWave % n;
-  const int total = ngames * n;
-  for (int c = lane; c < total; c += kWave) {
-    out[(g0 + g) * out_stride + e] = lds[g * S + e];
-    g += dg;
-    e += de;
-    if (e >= n) {
-      e -= n;
-      ++g;
-    }
-  }
+  copy_slab<T, false>(const_cast<T*>(lds), out, out_stride, n, S, g0, ngames, lane);
 }
 
 // host subset of game `g` -> c[0..d) (as T) ; returns the bitmask of entries == 1

@@ -15,8 +15,9 @@ from oracle import np_oracle as NO
 
 pytestmark = pytest.mark.gpu
 
-FAST_SPECS = [(4, 3), (5, 3), (10, 3), (16, 3), (20, 3), (8, 4), (20, 4), (50, 4)]
-GENERIC_SPECS = [(7, 3), (5, 2), (6, 5), (12, 6), (3, 3), (64, 3)]
+FAST_SPECS = [(4, 3), (5, 3), (10, 3), (16, 3), (20, 3), (8, 4), (20, 4)]   # register-resident kernels
+MID_SPECS = [(50, 4), (7, 3), (5, 2), (6, 5), (12, 6), (3, 3), (64, 3), (33, 4), (2, 2)]  # LDS-rows kernel (f32)
+GENERIC_SPECS = [(7, 3), (5, 2), (6, 5), (12, 6), (3, 3), (64, 3), (70, 3), (9, 7)]
 
 
 def dev(x, dtype=None):
@@ -194,17 +195,18 @@ def test_live_config1_trajectory(live_list, scale):
 # seeded random inputs against the C oracle: every mode, both kernel families
 # ------------------------------------------------------------------------------------------
 
-def _check_all_ops(rng, m, d, dtype, force_generic, b=97):
+def _check_all_ops(rng, m, d, dtype, force_generic, b=97, force_lds_rows=False):
     tdt = torch.float32 if dtype == np.float32 else torch.float64
     for sem in ("jax", "torch", "list"):
         for pad in (-1.0, -1e-8, -2.5):
             p = rand_state(rng, b, m, d, dtype, pad)
-            p[3, 1] = [-3.0] * d  # irregular padding rows, incl. a duplicated one
-            p[3, 2] = [-3.0] * d
+            if m >= 3:
+                p[3, 1] = [-3.0] * d  # irregular padding rows, incl. a duplicated one
+                p[3, 2] = [-3.0] * d
             if d > 1:
                 p[4, 0, 0] = -0.5  # a mixed-sign row
             P = dev(p)
-            kw = dict(sem=sem, padding_value=pad, force_generic=force_generic)
+            kw = dict(sem=sem, padding_value=pad, force_generic=force_generic, force_lds_rows=force_lds_rows)
             for compact in (False, True):
                 got = host(ops.get_newton_polytope(P, compact_sorted=compact, **kw))
                 assert np.array_equal(got, CO.get_newton_polytope(p, pad, sem=sem, compact_sorted=compact)), (sem, pad, compact)
@@ -217,7 +219,7 @@ def _check_all_ops(rng, m, d, dtype, force_generic, b=97):
                     want = CO.shift(p, cls, ax, pad, sem=sem, noop_if_invalid=noop, ignore_ended=ign)
                     got = ops.shift(P, dev(cls), dev(ax), noop_if_invalid=noop, ignore_ended=ign, **kw)
                     assert np.array_equal(host(got), want), (sem, pad, noop, ign)
-            fl = ops.make_flags(sem, force_generic=force_generic)
+            fl = ops.make_flags(sem, force_generic=force_generic, force_lds_rows=force_lds_rows)
             for stages in (A.HK_STAGE_SHIFT | A.HK_STAGE_NEWTON, 7, 15):
                 want = CO.step(p, cls, ax, stages=stages, flags=CO.flags_of(sem=sem), padding_value=pad, reward_sign=-1.0)
                 got = ops.step(P, dev(cls), dev(ax).to(tdt), stages=stages, flags=fl, padding_value=pad,
@@ -236,6 +238,34 @@ def test_random_vs_oracle_fast_specs(spec):
     assert ops.has_fast_path(m, d)
     rng = np.random.default_rng(100 * m + d)
     _check_all_ops(rng, m, d, np.float32, force_generic=False, b=97 if m < 50 else 70)
+
+
+@pytest.mark.parametrize("spec", [(20, 3), (10, 3), (8, 4), (4, 3)])
+def test_random_vs_oracle_lds_rows_on_fast_specs(spec):
+    """the LDS-rows kernel forced onto shapes that normally run register-resident"""
+    m, d = spec
+    rng = np.random.default_rng(17 * m + d)
+    _check_all_ops(rng, m, d, np.float32, force_generic=False, b=97, force_lds_rows=True)
+    P = ops.generate_points(3000, m, d, 20, seed=2)
+    cls = torch.randint(0, 2 ** d - d - 1, (3000,), device="cuda", dtype=torch.int32)
+    ax = torch.randint(0, d, (3000,), device="cuda", dtype=torch.int32)
+    a = ops.step(P, cls, ax, stages=7)["points"]
+    assert torch.equal(a, ops.step(P, cls, ax, stages=7, flags=A.HK_FLAG_FORCE_LDS_ROWS)["points"])
+    Q1, Q2 = P.clone(), P.clone()
+    r1 = ops.rollout(Q1, 15, 4, record=("axis", "done"))
+    r2 = ops.rollout(Q2, 15, 4, record=("axis", "done"), flags=A.HK_FLAG_FORCE_LDS_ROWS)
+    assert torch.equal(Q1, Q2) and torch.equal(r1["done"], r2["done"]) and torch.equal(r1["done_count"], r2["done_count"])
+    g1 = ops.generate_points(500, m, d, 20, seed=8)
+    assert torch.equal(g1, ops.generate_points(500, m, d, 20, seed=8, flags=A.HK_FLAG_FORCE_LDS_ROWS))
+
+
+@pytest.mark.parametrize("spec", MID_SPECS)
+def test_random_vs_oracle_mid_specs(spec):
+    """f32 shapes without a register specialisation run on the LDS-rows kernel (hk_mid_kernel.h)"""
+    m, d = spec
+    assert not ops.has_fast_path(m, d)
+    rng = np.random.default_rng(31 * m + d)
+    _check_all_ops(rng, m, d, np.float32, force_generic=False, b=70 if m < 50 else 67)
 
 
 @pytest.mark.parametrize("spec", GENERIC_SPECS + [(20, 3), (10, 3)])
@@ -275,7 +305,8 @@ def test_large_values_and_float_axis():
 # generator, fused rollout, sharding
 # ------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("spec,force_generic", [((20, 3), False), ((20, 3), True), ((10, 3), False), ((50, 4), False), ((7, 3), True)])
+@pytest.mark.parametrize("spec,force_generic", [((20, 3), False), ((20, 3), True), ((10, 3), False), ((50, 4), False),
+                                                ((7, 3), True), ((7, 3), False), ((12, 6), False)])
 def test_generate_matches_oracle(spec, force_generic):
     m, d = spec
     fl = A.HK_FLAG_FORCE_GENERIC if force_generic else 0
@@ -287,7 +318,8 @@ def test_generate_matches_oracle(spec, force_generic):
     assert np.array_equal(host(raw), NO.random_ints(300, m, d, 7, 1).astype(np.float32))
 
 
-@pytest.mark.parametrize("spec,force_generic", [((20, 3), False), ((20, 3), True), ((10, 3), False), ((8, 4), False), ((6, 5), True)])
+@pytest.mark.parametrize("spec,force_generic", [((20, 3), False), ((20, 3), True), ((10, 3), False), ((8, 4), False),
+                                                ((6, 5), True), ((50, 4), False), ((7, 3), False), ((6, 5), False)])
 def test_rollout_matches_oracle(spec, force_generic):
     m, d = spec
     fl = A.HK_FLAG_FORCE_GENERIC if force_generic else 0
