@@ -114,11 +114,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
+    # HK_BENCH_BACKEND=gloo rehearses the multi-rank flow on a box with fewer GPUs than ranks (ranks then
+    # share devices and the final gather is staged through host memory); the real path is nccl = RCCL.
+    backend = os.environ.get("HK_BENCH_BACKEND", "nccl")
+    device_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(device_index)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     from hironaka_amd import _abi as A
     from hironaka_amd import ops
@@ -130,7 +137,22 @@ def main():
     state = torch.empty_like(fresh)
     done_count = torch.zeros(EPISODE + 1, dtype=torch.int64, device="cuda")
     step_counts = torch.zeros((EPISODE, 2), dtype=torch.int64, device="cuda")
-    gathered = [torch.empty_like(state) for _ in range(world)] if distributed else None
+    from hironaka_amd import distributed as hkdist
+
+    def gather_final_states():
+        """the trainer boundary: every rank ends up with all B*world final states"""
+        if not distributed:
+            return state
+        if backend == "nccl":
+            return hkdist.all_gather_games(state)
+        return hkdist.all_gather_games(state.cpu())
+
+    def max_over_ranks(x: float) -> float:
+        if not distributed:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
     K, W = args.steps, args.warmup
     n_full, rem = divmod(K, EPISODE)
     kw = dict(game_offset=game_offset, stages=stages, host_policy=A.HK_HOST_RANDOM,
@@ -164,8 +186,7 @@ def main():
     # ---- warm-up (untimed) -------------------------------------------------------------------
     for _ in range(max(1, W // EPISODE)):
         g_episode.replay()
-    if distributed:
-        dist.all_gather(gathered, state)
+    gather_final_states()
     barrier()
 
     # ---- exactly K timed steps ---------------------------------------------------------------
@@ -181,17 +202,13 @@ def main():
     if g_rem is not None:
         g_rem.replay()
     ev1.record()
-    if distributed:
-        dist.all_gather(gathered, state)
+    final_states = gather_final_states()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     region_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream, around the K steps
-    if distributed:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    assert final_states.shape[0] == world * b
     finished = int(done_count[EPISODE].item()) // max(1, n_full) if n_full else 0
 
     # ---- the one-launch-per-step variant, timed separately (rank 0's shard) --------------------
