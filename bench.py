@@ -231,6 +231,49 @@ def main():
                   "note": "one launch of hk::fast_kernel<20,3,rollout> (T=1) + counter reduce per env step; "
                           "state read from and written to HBM every step"}
 
+    # ---- same kernels at the batch that saturates one GPU (BASELINE configs[3]'s 524 288 games on ONE
+    # device): one lane per game means 65 536 games are only 1024 instruction streams for 1024 SIMDs ----
+    large = None
+    if world == 1 and b == BATCH and not args.no_single_step:
+        bl = 8 * BATCH
+        fresh_l = ops.generate_points(bl, m, d, MAX_VALUE, seed=42)
+        state_l = torch.empty_like(fresh_l)
+        dc_l = torch.zeros(EPISODE + 1, dtype=torch.int64, device="cuda")
+        sc_l = torch.zeros((EPISODE, 2), dtype=torch.int64, device="cuda")
+        kw_l = dict(stages=stages, host_policy=A.HK_HOST_RANDOM, agent_policy=A.HK_AGENT_RANDOM)
+
+        def ep_fused():
+            ops.rollout(state_l, EPISODE, SEED, done_count=dc_l, initial=fresh_l, **kw_l)
+
+        def ep_steps():
+            for t in range(EPISODE):
+                ops.rollout(state_l, 1, SEED, step_offset=t, done_count=sc_l[t],
+                            initial=fresh_l if t == 0 else None, **kw_l)
+
+        with torch.cuda.stream(side):
+            ep_fused()
+            ep_steps()
+            torch.cuda.synchronize()
+            gf, gs = capture(ep_fused), capture(ep_steps)
+        torch.cuda.synchronize()
+        times = []
+        for gr in (gf, gs):
+            gr.replay()
+            torch.cuda.synchronize()
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            for _ in range(20):
+                gr.replay()
+            a1.record()
+            torch.cuda.synchronize()
+            times.append(a0.elapsed_time(a1) / 1e3 / (20 * EPISODE))
+        bs = algorithmic_bytes_per_step(m, d)
+        large = {"batch": bl, "fused_env_steps_per_s": bl / times[0], "single_step_env_steps_per_s": bl / times[1],
+                 "single_step_us": times[1] * 1e6, "single_step_algorithmic_GBps": bl * bs / times[1] / 1e9,
+                 "single_step_frac_of_hbm_peak": bl * bs / times[1] / 1e9 / HBM_PEAK_GBS,
+                 "note": "not the headline config: shows where the kernels saturate one MI355X"}
+        del fresh_l, state_l
+
     if rank == 0:
         bytes_step = algorithmic_bytes_per_step(m, d)
         launches = n_full + (1 if rem else 0)
@@ -281,6 +324,8 @@ def main():
         }
         if single is not None:
             out["single_step"] = single
+        if large is not None:
+            out["large_batch"] = large
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -72,7 +72,10 @@ int launch(Params& prm, int dtype, hipStream_t stream) {
 // number of workgroups `launch` will use for this request (0: not launchable)
 int64_t planned_grid(Params prm, int dtype) {
   if (prm.batch == 0) return 0;
-  if (fast_supported(prm, dtype)) return ((int64_t)prm.batch + kWave - 1) / kWave;
+  if (fast_supported(prm, dtype)) {
+    const int gpb = fast_games_per_block(prm);
+    return ((int64_t)prm.batch + gpb - 1) / gpb;
+  }
   if (mid_supported(prm, dtype) && plan_mid(prm) == HK_OK)
     return ((int64_t)prm.batch + prm.games_per_block - 1) / prm.games_per_block;
   if (plan_generic(prm, dtype) != HK_OK) return 0;

@@ -172,16 +172,16 @@ __device__ inline void fast_load_coords(const Params& prm, int64_t g, int m, flo
 // random / fixed policies of jax/players.py (not Zeillinger: that one runs on the generic kernel)
 // `cache` holds the Philox block of steps {2b, 2b+1}: the fused loop calls Philox every other step.
 template <int D>
-__device__ inline void fast_policy(const Params& prm, uint64_t gg, uint32_t step, PolicyCache& cache,
-                                   int& cls, int& axis, uint32_t& mask) {
+__device__ inline void fast_policy(uint64_t seed, int host_policy, int agent_policy, uint64_t gg, uint32_t step,
+                                   PolicyCache& cache, int& cls, int& axis, uint32_t& mask) {
   constexpr uint32_t ncls = (1u << D) - (uint32_t)D - 1u;
   uint32_t ra, rb;
-  policy_words(gg, step, prm.seed, cache, ra, rb);
-  cls = (prm.host_policy == HK_HOST_RANDOM) ? (int)mulhi32(ra, ncls) : (int)ncls - 1;
+  policy_words(gg, step, seed, cache, ra, rb);
+  cls = (host_policy == HK_HOST_RANDOM) ? (int)mulhi32(ra, ncls) : (int)ncls - 1;
   mask = decode_class(cls, D);
-  if (prm.agent_policy == HK_AGENT_RANDOM) {
+  if (agent_policy == HK_AGENT_RANDOM) {
     axis = (int)mulhi32(rb, (uint32_t)D);
-  } else if (prm.agent_policy == HK_AGENT_RANDOM_LEGAL) {
+  } else if (agent_policy == HK_AGENT_RANDOM_LEGAL) {
     const int pick = (int)mulhi32(rb, (uint32_t)__popc(mask));
     int seen = 0;
     axis = 0;
@@ -191,11 +191,17 @@ __device__ inline void fast_policy(const Params& prm, uint64_t gg, uint32_t step
         if (seen == pick) axis = k;
         ++seen;
       }
-  } else if (prm.agent_policy == HK_AGENT_CHOOSE_FIRST) {
+  } else if (agent_policy == HK_AGENT_CHOOSE_FIRST) {
     axis = __ffs(mask) - 1;
   } else {
     axis = 31 - __clz(mask);
   }
+}
+
+template <int D>
+__device__ inline void fast_policy(const Params& prm, uint64_t gg, uint32_t step, PolicyCache& cache,
+                                   int& cls, int& axis, uint32_t& mask) {
+  fast_policy<D>(prm.seed, prm.host_policy, prm.agent_policy, gg, step, cache, cls, axis, mask);
 }
 
 // ---- the kernel: MODE is one of kModeStep / kModeRollout / kModeGenerate -------------------------
@@ -205,9 +211,12 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
   __shared__ __align__(16) float lds[kWave * G::S];
   __shared__ float cbuf[kWave * D];  // slow path only: subset mask / row scratch per lane
   const int lane = threadIdx.x;
-  const int64_t g0 = (int64_t)blockIdx.x * kWave;
+  // games per wave: 64, or fewer (lanes idle) when the batch would otherwise leave the SIMDs with
+  // fewer than two waves each -- see fast_games_per_block()
+  const int gpb = prm.games_per_block;
+  const int64_t g0 = (int64_t)blockIdx.x * gpb;
   const int64_t left = (int64_t)prm.batch - g0;
-  const int ngames = (int)(left < kWave ? left : kWave);
+  const int ngames = (int)(left < gpb ? left : gpb);
   const bool active = lane < ngames;
   const int64_t g = g0 + lane;
   const uint64_t gg = prm.game_offset + (uint64_t)g;
@@ -323,10 +332,25 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
   }
 
   // ---- 4. the transitions --------------------------------------------------------------------------
+  // Wave-uniform facts about the optional outputs are computed ONCE: tested per step through the
+  // kernel-argument struct, SGPR pressure makes the compiler re-issue the 64-byte s_load of the pointer
+  // block (and a full s_waitcnt) several times per step.
+  const bool want_obs = (MODE == kModeRollout) && prm.obs_out != nullptr;
+  const bool want_records = (MODE == kModeRollout) && (prm.r_host_class_out || prm.r_axis_out ||
+                                                       prm.r_done_out || prm.r_reward_out);
+  uint32_t* count_slot = (MODE == kModeRollout && prm.count_ws) ? prm.count_ws + blockIdx.x : nullptr;
+  uint32_t count_stride = gridDim.x;
+  uint32_t step0 = prm.step_offset;
+  uint64_t seed = prm.seed;
+  int host_policy = prm.host_policy, agent_policy = prm.agent_policy;
+  // opaque to the optimiser: the values now "come from" the asm, so they stay in SGPRs (or a VGPR lane)
+  // instead of being re-loaded from the kernel-argument / dispatch memory inside the loop
+  asm volatile("" : "+s"(count_slot), "+s"(count_stride), "+s"(step0), "+s"(seed), "+s"(host_policy),
+               "+s"(agent_policy));
   for (int t = 0; t < nsteps; ++t) {
     int axis = -1, cls = 0;
     if (MODE == kModeRollout) {
-      if (prm.obs_out) {  // state before the step: rebuild the image, store it coalesced
+      if (want_obs) {  // state before the step: rebuild the image, store it coalesced
         __syncthreads();
         fill_image<M, D>(mine, pad);
         scatter_rows<M, G::C, D>(q, mine, gmask, nmax);
@@ -335,7 +359,7 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
                               g0, ngames, lane);
       }
       uint32_t mask;
-      fast_policy<D>(prm, gg, prm.step_offset + (uint32_t)t, pcache, cls, axis, mask);
+      fast_policy<D>(seed, host_policy, agent_policy, gg, step0 + (uint32_t)t, pcache, cls, axis, mask);
 #pragma unroll
       for (int k = 0; k < D; ++k) c[k] = (float)((mask >> k) & 1u);
     } else if (MODE == kModeStep) {
@@ -352,16 +376,16 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
     const bool done = np < 2;
     if (done && length < 0) length = t + 1;
     if (MODE == kModeRollout) {
-      if (active) {
+      if (want_records && active) {
         const int64_t at = (int64_t)t * prm.batch + g;
         if (prm.r_host_class_out) prm.r_host_class_out[at] = cls;
         if (prm.r_axis_out) prm.r_axis_out[at] = axis;
         if (prm.r_done_out) prm.r_done_out[at] = done;
         if (prm.r_reward_out) prm.r_reward_out[at] = prm.reward_sign * (float)(done && !prev_done);
       }
-      if (prm.count_ws) {
+      if (count_slot) {
         const unsigned long long bd = __ballot(active && done);
-        if (lane == 0) prm.count_ws[(size_t)(t + 1) * gridDim.x + blockIdx.x] = (uint32_t)__popcll(bd);
+        if (lane == 0) count_slot[(size_t)(t + 1) * count_stride] = (uint32_t)__popcll(bd);
       }
       // re-gather when the widest game of the wave got narrower (removed rows are holes until then)
       // (one ballot per step; the cross-lane maximum only when some game still fills all nmax rows)
@@ -413,9 +437,22 @@ bool fast_aligned_t(const Params& prm) {
   return true;
 }
 
+// One lane per game means one INSTRUCTION STREAM per 64 games; a wave's stream is latency-bound on its
+// own (~7.7 cycles per instruction measured, whether or not it shares its SIMD), so 65 536 games = 1024
+// waves leave the 1024 SIMDs half idle and the same kernels run ~2x more games per second at >= 262 144
+// games.  For long fused rollouts on small batches it is marginally faster (-3 %) to put 32 games in a
+// wave (half its lanes idle, two waves per SIMD); for a single step the doubled wave count costs more
+// than it gains.
+inline int fast_games_per_block(const Params& prm) {
+  constexpr int kSimds = 256 * 4;  // MI355X
+  const bool long_rollout = prm.mode == kModeRollout && prm.steps >= 8;
+  return (long_rollout && ((int64_t)prm.batch + kWave - 1) / kWave < 2 * kSimds) ? kWave / 2 : kWave;
+}
+
 template <int M, int D>
-int launch_fast_t(const Params& prm, hipStream_t stream) {
-  const unsigned grid = (unsigned)(((int64_t)prm.batch + kWave - 1) / kWave);
+int launch_fast_t(Params prm, hipStream_t stream) {
+  prm.games_per_block = fast_games_per_block(prm);
+  const unsigned grid = (unsigned)(((int64_t)prm.batch + prm.games_per_block - 1) / prm.games_per_block);
   launch_prepare();
   if (prm.mode == kModeStep)
     hipLaunchKernelGGL((fast_kernel<M, D, kModeStep>), dim3(grid), dim3(kWave), 0, stream, prm);
