@@ -114,14 +114,46 @@ def simulate_fixed_policies(key: int, role: str, *, spec: Tuple[int, int], batch
         coords = ops.decode_host_class(res["host_class"].reshape(-1), d, dtype).reshape(T, batch_size, d)
         obs = torch.cat([obs, coords], dim=-1)
         policy = torch.nn.functional.one_hot(res["axis"].long(), d).to(dtype)
-    length = res["game_length"].to(torch.int64)  # steps until done (0: at entry, -1: never)
-    t = torch.arange(T, device=obs.device).unsqueeze(1)
-    remaining = (length.unsqueeze(0) - 1 - t).clamp(min=0)  # moves left before the finishing one
-    finished = (length >= 0).unsqueeze(0)
-    npts = ops.get_num_points(pts).clamp(min=1).to(dtype)
-    tail = (T - 1 - t).to(dtype)
-    value = torch.where(finished, sign * discount ** remaining.to(dtype),
-                        sign / npts.unsqueeze(0) * discount ** tail)
+    # value targets exactly as rollout_postprocess computes them from the observed point counts
+    num_points = ops.get_num_points(res["obs"].reshape(T * batch_size, m, d)).reshape(T, batch_size).transpose(0, 1)
+    value = calculate_value_using_reward_fn(num_points, discount, role, use_unified_tree=False).to(dtype)
     # [T, B, .] -> [B*T, .] in the reference's (batch-major) order
     to_bt = lambda x: x.transpose(0, 1).reshape(batch_size * T, *x.shape[2:])
-    return to_bt(obs), to_bt(policy), to_bt(value)
+    return to_bt(obs), to_bt(policy), value.reshape(batch_size * T)
+
+
+def calculate_value_using_reward_fn(num_points: torch.Tensor, discount: float, role: str,
+                                    use_unified_tree: bool) -> torch.Tensor:
+    """jax/util.py:261-284 with the reward / estimate functions rollout_postprocess selects
+    (jax_trainer.py:583-584).  num_points [B, T] (points alive at each recorded state) -> values [B, T]:
+    discounted reward of the finishing move for games that end inside the rollout (constant, with the
+    clipped discount table, after the end) + sign/num_points * discount^(T-1-t) for those that do not."""
+    if role not in ("host", "agent"):
+        raise ValueError(f"role must be either host or agent. Got {role}.")
+    b, t = num_points.shape
+    dev = num_points.device
+    done = num_points <= 1
+    next_done = torch.cat([done[:, 1:], torch.zeros((b, 1), dtype=torch.bool, device=dev)], dim=1)
+    rew = (next_done & ~done).to(torch.float32)
+    if use_unified_tree or role == "agent":
+        rew = -rew  # agent reward (util.py:141-144); the unified tree always uses the agent's
+    steps = torch.arange(t, device=dev, dtype=torch.float32)
+    disc = torch.tensor(-discount if use_unified_tree else discount, dtype=torch.float32, device=dev)
+    table = torch.clamp(torch.pow(disc, steps.reshape(1, -1) - steps.reshape(-1, 1)), -1.0, 1.0)
+    discounted = rew @ table.T
+    sign = (-1) ** (t + 1) if use_unified_tree else 1
+    role_sign = 1.0 if role == "host" else -1.0
+    est = (role_sign / num_points[:, -1].clamp(min=1).to(torch.float32)).unsqueeze(1) * sign
+    unfinished = (~done[:, -1:]).to(torch.float32) * est * torch.pow(disc, steps.flip(0)).unsqueeze(0)
+    return discounted + unfinished
+
+
+def rollout_postprocess(rollouts, role: str, dimension: int, discount: float = 0.99, use_unified_tree: bool = True):
+    """JAXTrainer.rollout_postprocess (jax_trainer.py:558-592): replace the value prior by the ground-truth
+    value from win/lose.  (obs [B, T, obs_dim], policy [B, T, A], value [B, T]) -> ([B*T, obs_dim],
+    [B*T, A], [B*T])."""
+    obs, policy, value = rollouts
+    offset = 1 if (use_unified_tree or role == "agent") else 0
+    num_points = (obs >= 0).sum(dim=-1) // dimension - offset
+    new_value = calculate_value_using_reward_fn(num_points, discount, role, use_unified_tree).to(value.dtype)
+    return obs.reshape(-1, obs.shape[2]), policy.reshape(-1, policy.shape[2]), new_value.reshape(-1)

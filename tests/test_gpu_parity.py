@@ -425,3 +425,84 @@ def test_error_behaviour():
     assert ops.get_newton_polytope(torch.zeros(0, 5, 3, device="cuda")).shape == (0, 5, 3)  # empty batch
     h = torch.zeros(4, 5, 3, device="cuda", dtype=torch.float16)
     assert ops.get_newton_polytope(h).dtype == torch.float16
+
+
+# ------------------------------------------------------------------------------------------
+# ragged batches, degenerate shapes, high dimensions
+# ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("b", [1, 2, 31, 32, 33, 63, 64, 65, 127, 129, 1000])
+def test_ragged_batch_sizes(b):
+    """batches that do not fill the last wave (or even one wave), every kernel family, step + rollout +
+    generate; also checks nothing is written past the batch (guard rows after the tensors)."""
+    for (m, d), flag_sets in (((20, 3), (0, A.HK_FLAG_FORCE_LDS_ROWS, A.HK_FLAG_FORCE_GENERIC)),
+                              ((50, 4), (0, A.HK_FLAG_FORCE_GENERIC)), ((7, 5), (0, A.HK_FLAG_FORCE_GENERIC))):
+        p0 = CO.generate_points(b, m, d, 20, 3, game_offset=9)
+        rng = np.random.default_rng(b)
+        cls = rng.integers(0, 2 ** d - d - 1, b).astype(np.int32)
+        ax = rng.integers(0, d, b).astype(np.int32)
+        want = CO.step(p0, cls, ax, stages=7)
+        want_roll, want_rec = CO.rollout(p0, 5, 11, game_offset=9)
+        for fl in flag_sets:
+            guard = torch.full((b + 2, m, d), 123.0, device="cuda")
+            guard[:b] = dev(p0)
+            out = torch.full((b + 2, m, d), 456.0, device="cuda")
+            res = ops.step(guard[:b], dev(cls), dev(ax), stages=7, flags=fl, out=out[:b], want=("done", "reward"))
+            assert np.array_equal(host(out[:b]), want["points"]), (m, d, fl)
+            assert bool((out[b:] == 456.0).all()) and bool((guard[b:] == 123.0).all())
+            assert np.array_equal(host(res["done"]), want["done"])
+            roll = guard.clone()
+            rec = ops.rollout(roll[:b], 5, 11, game_offset=9, flags=fl, record=("axis", "game_length"))
+            assert np.array_equal(host(roll[:b]), want_roll) and bool((roll[b:] == 123.0).all()), (m, d, fl)
+            assert np.array_equal(host(rec["axis"]), want_rec["axis"])
+            assert np.array_equal(host(rec["game_length"]), want_rec["game_length"])
+            assert np.array_equal(host(rec["done_count"]).astype(np.uint64), want_rec["done_count"])
+            gen = torch.full((b + 1, m, d), 7.0, device="cuda")
+            ops.generate_points(b, m, d, 20, seed=3, game_offset=9, flags=fl, out=gen[:b])
+            assert np.array_equal(host(gen[:b]), p0) and bool((gen[b:] == 7.0).all())
+
+
+@pytest.mark.parametrize("spec", [(1, 3), (1, 2), (2, 10), (5, 10), (3, 8), (64, 2), (40, 6)])
+def test_degenerate_and_high_dim_shapes(spec):
+    """one-row games (always finished), dim up to the codec's limit of 10, 64 rows"""
+    m, d = spec
+    rng = np.random.default_rng(m * 100 + d)
+    b = 130
+    for dtype in (np.float32, np.float64):
+        p = rand_state(rng, b, m, d, dtype, -1.0, maxv=4, holes=0.2)
+        cls = rng.integers(0, 2 ** d - d - 1, b).astype(np.int32)
+        ax = rng.integers(0, d, b).astype(np.int32)
+        for sem in ("jax", "torch", "list"):
+            want = CO.step(p, cls, ax, stages=15, flags=CO.flags_of(sem=sem, noop_if_invalid=(sem != "jax")))
+            got = ops.step(dev(p), dev(cls), dev(ax), stages=15, flags=ops.make_flags(sem, noop_if_invalid=(sem != "jax")),
+                           want=("done", "num_points"))
+            assert np.array_equal(host(got["points"]), want["points"]), (spec, dtype, sem)
+            assert np.array_equal(host(got["done"]), want["done"])
+            assert np.array_equal(host(got["num_points"]), want["num_points"])
+    q = CO.generate_points(b, m, d, 9, 1)
+    assert np.array_equal(host(ops.generate_points(b, m, d, 9, seed=1)), q)
+    wp, wr = CO.rollout(q, 4, 2, agent_policy=A.HK_AGENT_RANDOM_LEGAL)
+    Q = dev(q)
+    gr = ops.rollout(Q, 4, 2, agent_policy=A.HK_AGENT_RANDOM_LEGAL, record=("host_class", "axis"))
+    assert np.array_equal(host(Q), wp) and np.array_equal(host(gr["host_class"]), wr["host_class"])
+    assert np.array_equal(host(gr["axis"]), wr["axis"])
+
+
+def test_non_finite_and_negative_zero_inputs_take_the_exact_path():
+    """inf / NaN / -0.0 rows are outside the shortcut's exactness guard: all kernel families must agree with
+    each other (the generic routines decide) and finite games in the same batch must match the oracle."""
+    rng = np.random.default_rng(4)
+    b, m, d = 200, 20, 3
+    p = rand_state(rng, b, m, d, np.float32, -1.0)
+    p[5, 0] = [np.inf, 1, 2]
+    p[70, 3] = [np.nan, 0, 0]
+    p[140, 2] = [-0.0, 1, 1]
+    cls = rng.integers(0, 4, b).astype(np.int32)
+    ax = rng.integers(0, 3, b).astype(np.int32)
+    outs = [host(ops.step(dev(p), dev(cls), dev(ax), stages=7, flags=fl)["points"])
+            for fl in (0, A.HK_FLAG_FORCE_LDS_ROWS, A.HK_FLAG_FORCE_GENERIC)]
+    assert np.array_equal(outs[0], outs[1], equal_nan=True) and np.array_equal(outs[0], outs[2], equal_nan=True)
+    clean = np.ones(b, dtype=bool)
+    clean[[5, 70]] = False
+    want = CO.step(p, cls, ax, stages=7)["points"]
+    assert np.array_equal(outs[0][clean], want[clean])

@@ -1,6 +1,7 @@
 """Pin the oracle (numpy + C restatements) to the reference: hand-typed known answers from
 the reference's own tests, outputs of the reference's torch/list siblings (live_*.npz), the
 reference's native cppUtil (oracle/_ref, when built), and each other."""
+import json
 import os
 import ctypes
 
@@ -422,3 +423,33 @@ def test_philox_known_answer():
     assert [int(x) for x in out] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
     out = NO.philox4x32(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, (0x299F31D0 << 32) | 0xA4093822)
     assert [int(x) for x in out] == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def _postprocess_cases():
+    with open(os.path.join(ROOT, "tests", "golden", "rollout_postprocess.json")) as f:
+        doc = json.load(f)
+    return doc["dimension"], doc["discount"], doc["cases"]
+
+
+def test_rollout_postprocess_reference_vectors():
+    """the value targets of JAXTrainer.rollout_postprocess, against the literal arrays of
+    the reference's test_rollout_postprocess (test/testJAXTrainer.py:91-389, extracted as data by
+    tests/golden/extract_postprocess_vectors.py).  Oracle and the product's torch plumbing both."""
+    import torch
+    from hironaka_amd.rollout import rollout_postprocess
+
+    dimension, discount, cases = _postprocess_cases()
+    assert len(cases) == 5
+    for case in cases:
+        obs = np.asarray(case["obs"], dtype=np.float32)
+        want = np.asarray(case["expected"], dtype=np.float32).ravel()
+        got = NO.rollout_postprocess(obs, dimension, discount, case["role"], case["unified"])
+        assert got.shape == want.shape and np.allclose(got, want, rtol=0, atol=1e-6)
+        b, t, w = obs.shape
+        tobs = torch.from_numpy(obs)
+        o, p, v = rollout_postprocess((tobs, torch.zeros(b, t, 4), torch.zeros(b, t)), case["role"], dimension,
+                                      discount, case["unified"])
+        assert o.shape == (b * t, w) and p.shape == (b * t, 4) and v.shape == (b * t,)
+        assert np.allclose(v.numpy(), want, rtol=0, atol=1e-6)
+    with pytest.raises(ValueError):
+        NO.rollout_postprocess(obs, dimension, discount, "referee", False)
