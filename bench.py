@@ -231,6 +231,59 @@ def main():
                   "note": "one launch of hk::fast_kernel<20,3,rollout> (T=1) + counter reduce per env step; "
                           "state read from and written to HBM every step"}
 
+    def time_boundary_steps(start, n_ep):
+        """seconds per hk_step launch, over episodes of EPISODE steps from `start` with pre-drawn actions"""
+        nb = start.shape[0]
+        cls = torch.randint(0, 2 ** d - d - 1, (EPISODE, nb), dtype=torch.int32, device="cuda")
+        masks = ops.decode_host_class(cls.reshape(-1), d, torch.float32).reshape(EPISODE, nb, d).contiguous()
+        axes = torch.randint(0, d, (EPISODE, nb), dtype=torch.int32, device="cuda")
+        bufs = [torch.empty_like(start), torch.empty_like(start)]
+
+        def episode_api():
+            src = start
+            for t in range(EPISODE):
+                ops.step(src, masks[t], axes[t], stages=stages, out=bufs[t & 1], want=("done", "reward"))
+                src = bufs[t & 1]
+
+        with torch.cuda.stream(side):
+            episode_api()
+            torch.cuda.synchronize()
+            g_api = capture(episode_api)
+        torch.cuda.synchronize()
+        g_api.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n_ep):
+            g_api.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 1e3 / (n_ep * EPISODE)
+
+    # ---- the drop-in boundary itself: hk_step with the trainer's arrays (state in, [B,d] subset mask and
+    # [B] axis in, state + done + reward out) -- exactly SURVEY 8(d)'s 501 algorithmic bytes per env step ----
+    api = None
+    if g_stepwise is not None:
+        api_s = time_boundary_steps(fresh, max(1, min(n_full, 50)))
+        # what a plain device-to-device copy reaches on this box (read + write bytes per second)
+        big = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+        dst = torch.empty_like(big)
+        dst.copy_(big)
+        torch.cuda.synchronize()
+        s0.record()
+        for _ in range(10):
+            dst.copy_(big)
+        s1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 10 * 2 * big.numel() * 4 / (s0.elapsed_time(s1) / 1e3) / 1e9
+        del big, dst
+        gbps = b * algorithmic_bytes_per_step(m, d) / api_s / 1e9
+        api = {"value": b / api_s, "unit": "env-steps/s per GPU", "us_per_step": api_s * 1e6,
+               "steps": max(1, min(n_full, 50)) * EPISODE, "algorithmic_GBps": gbps,
+               "frac_of_hbm_peak": gbps / HBM_PEAK_GBS, "device_copy_GBps": copy_gbps, "frac_of_device_copy": gbps / copy_gbps,
+               "note": "one hk_step launch per env step (hk::fast_kernel<20,3,step>): f32 state + f32 [B,d] mask "
+                       "+ i32 axis read from HBM, state + done + reward written back"}
+
     # ---- same kernels at the batch that saturates one GPU (BASELINE configs[3]'s 524 288 games on ONE
     # device): one lane per game means 65 536 games are only 1024 instruction streams for 1024 SIMDs ----
     large = None
@@ -268,7 +321,9 @@ def main():
             torch.cuda.synchronize()
             times.append(a0.elapsed_time(a1) / 1e3 / (20 * EPISODE))
         bs = algorithmic_bytes_per_step(m, d)
-        large = {"batch": bl, "fused_env_steps_per_s": bl / times[0], "single_step_env_steps_per_s": bl / times[1],
+        api_l = time_boundary_steps(fresh_l, 20)
+        large = {"batch": bl, "boundary_step_us": api_l * 1e6,
+                 "boundary_step_frac_of_hbm_peak": bl * bs / api_l / 1e9 / HBM_PEAK_GBS, "fused_env_steps_per_s": bl / times[0], "single_step_env_steps_per_s": bl / times[1],
                  "single_step_us": times[1] * 1e6, "single_step_algorithmic_GBps": bl * bs / times[1] / 1e9,
                  "single_step_frac_of_hbm_peak": bl * bs / times[1] / 1e9 / HBM_PEAK_GBS,
                  "note": "not the headline config: shows where the kernels saturate one MI355X"}
@@ -324,6 +379,8 @@ def main():
         }
         if single is not None:
             out["single_step"] = single
+        if api is not None:
+            out["boundary_step"] = api
         if large is not None:
             out["large_batch"] = large
         if world == 1 and not args.no_cpu_baseline:

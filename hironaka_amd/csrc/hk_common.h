@@ -148,6 +148,44 @@ __device__ inline double load_scalar(const void* base, int dtype, size_t idx) {
   return 0.0;
 }
 
+// The same fetch split in two, branch-free in the part that touches memory: `fetch_raw` requests the
+// aligned dword(s) holding element idx (the upper request repeats the lower one for elements narrower
+// than 8 bytes, so every address is inside the caller's array's own words), and nothing looks at the
+// bits until `scalar_from_raw`.  Fetches of any mix of dtypes therefore stay in flight together with
+// whatever is issued next -- a dtype switch around the loads would end every case in a wait.
+struct RawScalar {
+  uint32_t lo, hi, shift;
+};
+
+__device__ inline int dtype_size(int dtype) {
+  return (dtype == HK_F64 || dtype == HK_I64) ? 8 : (dtype == HK_U8 ? 1 : 4);
+}
+
+__device__ inline RawScalar fetch_raw(const void* base, int dtype, size_t idx) {
+  const int esz = dtype_size(dtype);
+  // pointer arithmetic only (an integer round trip would turn these into flat loads)
+  const char* p = static_cast<const char*>(base) + idx * (size_t)esz;
+  const uint32_t off = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u);
+  const uint32_t* lo = reinterpret_cast<const uint32_t*>(p - off);
+  const uint32_t* hi = lo + (esz == 8 ? 1 : 0);
+  RawScalar r;
+  r.lo = *lo;
+  r.hi = *hi;
+  r.shift = off * 8u;
+  return r;
+}
+
+__device__ inline double scalar_from_raw(const RawScalar& r, int dtype) {
+  switch (dtype) {
+    case HK_F32: return (double)__uint_as_float(r.lo);
+    case HK_F64: return __longlong_as_double((long long)(((uint64_t)r.hi << 32) | r.lo));
+    case HK_I32: return (double)(int32_t)r.lo;
+    case HK_I64: return (double)(long long)(((uint64_t)r.hi << 32) | r.lo);
+    case HK_U8: return (double)((r.lo >> r.shift) & 0xFFu);
+  }
+  return 0.0;
+}
+
 // `arange(d) == axis` (_jax_ops.py:79): non-integral / out-of-range values match nothing.
 __device__ inline int axis_index(double a, int d) {
   if (!(a >= 0.0) || a >= (double)d || a != floor(a)) return -1;

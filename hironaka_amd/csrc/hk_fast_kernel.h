@@ -54,9 +54,12 @@ struct FastGeom {
   static constexpr int C = (M <= 32) ? M : 32;
 };
 
+// native vector types (usable as inline-asm register operands)
+typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef float vf2 __attribute__((ext_vector_type(2)));
 template <int W> struct VecOf;
-template <> struct VecOf<4> { using type = float4; };
-template <> struct VecOf<2> { using type = float2; };
+template <> struct VecOf<4> { using type = vf4; };
+template <> struct VecOf<2> { using type = vf2; };
 template <> struct VecOf<1> { using type = float; };
 
 // wave-wide maximum of a small int in [0, hi], returned in an SGPR: a downward search with one
@@ -71,36 +74,73 @@ __device__ inline int wave_max(int v, int hi) {
 }
 
 // ---- slab I/O ---------------------------------------------------------------------------------------
-template <int M, int D>
+// A lone wave per SIMD hides no latency by itself, so the whole slab is requested before the first
+// dependent instruction: Q wide loads per lane in flight together (one HBM round trip per launch, not
+// one per request).  Chunks past a partial slab re-read its last chunk (always a valid address) and
+// are simply not written to the image.
+template <int M, int D, bool ALL_IN_FLIGHT = true>
 __device__ inline void fast_load_slab(float* lds, const float* in, int64_t in_stride, int64_t g0,
                                       int ngames, int lane) {
   using G = FastGeom<M, D>;
   using V = typename VecOf<G::W>::type;
   const int total = ngames * G::Q;
+  if (!ALL_IN_FLIGHT) {
+#pragma unroll
+    for (int it = 0; it < G::Q; ++it) {
+      const int q = lane + it * kWave;
+      if (q < total) {
+        const int g = q / G::Q, c = q - g * G::Q;
+        const V v = *reinterpret_cast<const V*>(in + (g0 + g) * in_stride + c * G::W);
+        *reinterpret_cast<V*>(lds + g * G::S + c * G::W) = v;
+      }
+    }
+    return;
+  }
+  V v[G::Q];
+#pragma unroll
+  for (int it = 0; it < G::Q; ++it) {
+    int q = lane + it * kWave;
+    q = q < total ? q : total - 1;
+    const int g = q / G::Q, c = q - g * G::Q;
+    v[it] = *reinterpret_cast<const V*>(in + (g0 + g) * in_stride + c * G::W);
+  }
+  // an opaque use of every chunk right here: otherwise the compiler sinks each load into the
+  // conditional block of its store and waits for it there, one round trip per chunk
+#pragma unroll
+  for (int it = 0; it < G::Q; ++it) asm volatile("" : "+v"(v[it]));
 #pragma unroll
   for (int it = 0; it < G::Q; ++it) {
     const int q = lane + it * kWave;
-    if (q < total) {
-      const int g = q / G::Q, c = q - g * G::Q;
-      const V v = *reinterpret_cast<const V*>(in + (g0 + g) * in_stride + c * G::W);
-      *reinterpret_cast<V*>(lds + g * G::S + c * G::W) = v;
-    }
+    const int g = q / G::Q, c = q - g * G::Q;
+    if (q < total) *reinterpret_cast<V*>(lds + g * G::S + c * G::W) = v[it];
   }
 }
 
+// Stores need no such care (nothing waits for them); the image is read a few chunks at a time so that a
+// store inside the rollout loop (per-step observations) adds little to the loop's register pressure.
 template <int M, int D>
 __device__ inline void fast_store_slab(const float* lds, float* out, int64_t out_stride, int64_t g0,
                                        int ngames, int lane) {
   using G = FastGeom<M, D>;
   using V = typename VecOf<G::W>::type;
+  constexpr int kBatch = 4;
   const int total = ngames * G::Q;
 #pragma unroll
-  for (int it = 0; it < G::Q; ++it) {
-    const int q = lane + it * kWave;
-    if (q < total) {
+  for (int i0 = 0; i0 < G::Q; i0 += kBatch) {
+    V v[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {  // the image holds kWave games whatever ngames is
+      const int q = lane + (i0 + u < G::Q ? i0 + u : G::Q - 1) * kWave;
       const int g = q / G::Q, c = q - g * G::Q;
-      const V v = *reinterpret_cast<const V*>(lds + g * G::S + c * G::W);
-      *reinterpret_cast<V*>(out + (g0 + g) * out_stride + c * G::W) = v;
+      v[u] = *reinterpret_cast<const V*>(lds + g * G::S + c * G::W);
+    }
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) asm volatile("" : "+v"(v[u]));
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const int q = lane + (i0 + u) * kWave;
+      const int g = q / G::Q, c = q - g * G::Q;
+      if (i0 + u < G::Q && q < total) *reinterpret_cast<V*>(out + (g0 + g) * out_stride + c * G::W) = v[u];
     }
   }
 }
@@ -147,26 +187,52 @@ __device__ inline void fill_image(float* mine, float pad) {
   for (int c = 0; c < G::Q; ++c) *reinterpret_cast<V*>(mine + c * G::W) = v;
 }
 
+// The caller's actions of one game, as fetched (hk_step): raw bits, converted only after the slab
+// requests have been issued so that all of it shares one HBM round trip.
 template <int D>
-__device__ inline void fast_load_coords(const Params& prm, int64_t g, int m, float (&c)[D]) {
+struct RawActions {
+  RawScalar c[D];
+  RawScalar axis;
+};
+
+__device__ inline int coords_dtype(int kind) {
+  return kind == HK_COORDS_CLASS_I32 ? HK_I32
+         : (kind == HK_COORDS_CLASS_I64 ? HK_I64 : (kind == HK_COORDS_IN_RECORD ? HK_F32 : kind));
+}
+
+template <int D>
+__device__ inline void fast_fetch_actions(const Params& prm, int64_t g, int m, RawActions<D>& r) {
+  const int kind = prm.coords_kind;
+  const bool is_class = kind == HK_COORDS_CLASS_I32 || kind == HK_COORDS_CLASS_I64;
+  const bool in_record = kind == HK_COORDS_IN_RECORD;
+  const void* base = in_record ? prm.in : prm.coords;
+  // element index of the first value; class ids: one value per game (fetched D times, same address)
+  const size_t first = is_class ? (size_t)g
+                                : (size_t)(in_record ? g * prm.in_stride + (int64_t)m * D : g * prm.coords_stride);
+  const size_t step = is_class ? 0 : 1;
+  const int dt = coords_dtype(kind);
+#pragma unroll
+  for (int k = 0; k < D; ++k) r.c[k] = fetch_raw(base, dt, first + step * k);
+  r.axis = fetch_raw(prm.axis, prm.axis_dtype, (size_t)g);
+}
+
+template <int D>
+__device__ inline void fast_decode_actions(const Params& prm, const RawActions<D>& r, float (&c)[D], int& axis) {
   const int kind = prm.coords_kind;
   if (kind == HK_COORDS_CLASS_I32 || kind == HK_COORDS_CLASS_I64) {
-    long long cls = (kind == HK_COORDS_CLASS_I32) ? (long long)((const int32_t*)prm.coords)[g]
-                                                  : ((const long long*)prm.coords)[g];
+    long long cls = (kind == HK_COORDS_CLASS_I32) ? (long long)(int32_t)r.c[0].lo
+                                                  : (long long)(((uint64_t)r.c[0].hi << 32) | r.c[0].lo);
     constexpr long long ncls = (1ll << D) - D - 1;
     cls = cls < 0 ? 0 : (cls >= ncls ? ncls - 1 : cls);
     const uint32_t v = decode_class((int)cls, D);
 #pragma unroll
     for (int k = 0; k < D; ++k) c[k] = (float)((v >> k) & 1u);
-  } else if (kind == HK_COORDS_IN_RECORD) {
-    const float* rec = (const float*)prm.in + g * prm.in_stride + (int64_t)m * D;
-#pragma unroll
-    for (int k = 0; k < D; ++k) c[k] = rec[k];
   } else {
+    const int dt = coords_dtype(kind);
 #pragma unroll
-    for (int k = 0; k < D; ++k)
-      c[k] = (float)load_scalar(prm.coords, kind, (size_t)(g * prm.coords_stride + k));
+    for (int k = 0; k < D; ++k) c[k] = (float)scalar_from_raw(r.c[k], dt);
   }
+  axis = axis_index(scalar_from_raw(r.axis, prm.axis_dtype), D);
 }
 
 // random / fixed policies of jax/players.py (not Zeillinger: that one runs on the generic kernel)
@@ -233,10 +299,9 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
   int axis_in = -1;
 #pragma unroll
   for (int k = 0; k < D; ++k) c[k] = 0.0f;
-  if (MODE == kModeStep && (stages & HK_STAGE_SHIFT) && active) {
-    fast_load_coords<D>(prm, g, M, c);
-    axis_in = axis_index(load_scalar(prm.axis, prm.axis_dtype, (size_t)g), D);
-  }
+  RawActions<D> raw;
+  const bool fetch_actions = MODE == kModeStep && (stages & HK_STAGE_SHIFT) && active;
+  if (fetch_actions) fast_fetch_actions<D>(prm, g, M, raw);
 
   // ---- 1. the image --------------------------------------------------------------------------------
   if (MODE == kModeGenerate) {
@@ -250,8 +315,9 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
         if (e + qd < M * D) mine[e + qd] = (float)mulhi32(w[qd], (uint32_t)prm.max_value);
     }
   } else {
-    fast_load_slab<M, D>(lds, (const float*)prm.in, prm.in_stride, g0, ngames, lane);
+    fast_load_slab<M, D, MODE == kModeStep>(lds, (const float*)prm.in, prm.in_stride, g0, ngames, lane);
   }
+  if (fetch_actions) fast_decode_actions<D>(prm, raw, c, axis_in);
   __syncthreads();
 
   // ---- 2. live rows, exactness guard ------------------------------------------------------------
@@ -440,13 +506,19 @@ bool fast_aligned_t(const Params& prm) {
 // One lane per game means one INSTRUCTION STREAM per 64 games; a wave's stream is latency-bound on its
 // own (~7.7 cycles per instruction measured, whether or not it shares its SIMD), so 65 536 games = 1024
 // waves leave the 1024 SIMDs half idle and the same kernels run ~2x more games per second at >= 262 144
-// games.  For long fused rollouts on small batches it is marginally faster (-3 %) to put 32 games in a
-// wave (half its lanes idle, two waves per SIMD); for a single step the doubled wave count costs more
-// than it gains.
+// games.  Putting fewer games in a wave (idle lanes, more waves) does not buy that back: measured at
+// 65 536 games, 64/32/16 games per wave give 50.4/50.7/84.8 us per 20-step rollout and 11.6/12.3/18.5 us
+// per hk_step, so a wave always takes 64 games.
 inline int fast_games_per_block(const Params& prm) {
   constexpr int kSimds = 256 * 4;  // MI355X
-  const bool long_rollout = prm.mode == kModeRollout && prm.steps >= 8;
-  return (long_rollout && ((int64_t)prm.batch + kWave - 1) / kWave < 2 * kSimds) ? kWave / 2 : kWave;
+  // tuning hook (scripts/probe_stages.py): HK_FAST_GAMES_PER_WAVE=16|32|64 overrides the heuristic
+  static const int forced = [] {
+    const char* e = getenv("HK_FAST_GAMES_PER_WAVE");
+    const int v = e ? atoi(e) : 0;
+    return (v == 16 || v == 32 || v == 64) ? v : 0;
+  }();
+  if (forced) return forced;
+  return kWave;
 }
 
 template <int M, int D>

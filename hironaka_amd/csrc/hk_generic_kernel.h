@@ -43,9 +43,19 @@ __device__ inline void copy_slab(T* lds, T* glob, int64_t gstride, int n, int S,
         ++g;
       }
     }
+    // requests past the end repeat the batch's first (valid) one, so every load is unconditional and
+    // the whole batch is in flight before the opaque use below; a load left inside its `if` is sunk
+    // next to its store by the compiler and waited for there, one round trip per element
 #pragma unroll
-    for (int u = 0; u < kSlabBatch; ++u)
-      if (c0 + u * kWave < total) v[u] = TO_LDS ? glob[go[u]] : lds[lo[u]];
+    for (int u = 1; u < kSlabBatch; ++u)
+      if (c0 + u * kWave >= total) {
+        lo[u] = lo[0];
+        go[u] = go[0];
+      }
+#pragma unroll
+    for (int u = 0; u < kSlabBatch; ++u) v[u] = TO_LDS ? glob[go[u]] : lds[lo[u]];
+#pragma unroll
+    for (int u = 0; u < kSlabBatch; ++u) asm volatile("" : "+v"(v[u]));
 #pragma unroll
     for (int u = 0; u < kSlabBatch; ++u)
       if (c0 + u * kWave < total) {

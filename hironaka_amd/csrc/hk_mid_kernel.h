@@ -59,7 +59,7 @@ constexpr int mid_row_width() { return D == 4 ? 4 : (D == 2 ? 2 : 1); }
 // The loop is rolled (n is a run-time value), so it is batched by hand: kCopyBatch independent
 // requests per lane are issued before the first dependent LDS access, otherwise every iteration would
 // expose a full HBM latency (measured: 273 us instead of ~80 us for the (50,4) slab copy).
-constexpr int kCopyBatch = 8;
+constexpr int kCopyBatch = 16;
 
 template <bool TO_LDS>
 __device__ inline void mid_copy_slab(float* lds, float* glob, int64_t gstride, int n, int S, int64_t g0,
@@ -71,7 +71,7 @@ __device__ inline void mid_copy_slab(float* lds, float* glob, int64_t gstride, i
     const int dg = kWave / Q, dc = kWave % Q;
     const int total = ngames * Q;
     for (int q0 = lane; q0 < total; q0 += kWave * kCopyBatch) {
-      float4 v[kCopyBatch];
+      vf4 v[kCopyBatch];
       int lo[kCopyBatch];
       int64_t go[kCopyBatch];
 #pragma unroll
@@ -82,26 +82,33 @@ __device__ inline void mid_copy_slab(float* lds, float* glob, int64_t gstride, i
         c += dc;
         if (c >= Q) { c -= Q; ++g; }
       }
+      // unconditional requests (see copy_slab): past the end, repeat the batch's first one
+#pragma unroll
+      for (int u = 1; u < kCopyBatch; ++u)
+        if (q0 + u * kWave >= total) {
+          lo[u] = lo[0];
+          go[u] = go[0];
+        }
 #pragma unroll
       for (int u = 0; u < kCopyBatch; ++u) {
-        if (q0 + u * kWave < total) {
-          if (TO_LDS) {
-            v[u] = *reinterpret_cast<const float4*>(glob + go[u]);
-          } else if (lds4) {
-            v[u] = *reinterpret_cast<const float4*>(lds + lo[u]);
-          } else {
-            const float* l = lds + lo[u];
-            v[u] = make_float4(l[0], l[1], l[2], l[3]);
-          }
+        if (TO_LDS) {
+          v[u] = *reinterpret_cast<const vf4*>(glob + go[u]);
+        } else if (lds4) {
+          v[u] = *reinterpret_cast<const vf4*>(lds + lo[u]);
+        } else {
+          const float* l = lds + lo[u];
+          v[u] = vf4{l[0], l[1], l[2], l[3]};
         }
       }
+#pragma unroll
+      for (int u = 0; u < kCopyBatch; ++u) asm volatile("" : "+v"(v[u]));
 #pragma unroll
       for (int u = 0; u < kCopyBatch; ++u) {
         if (q0 + u * kWave < total) {
           if (!TO_LDS) {
-            *reinterpret_cast<float4*>(glob + go[u]) = v[u];
+            *reinterpret_cast<vf4*>(glob + go[u]) = v[u];
           } else if (lds4) {
-            *reinterpret_cast<float4*>(lds + lo[u]) = v[u];
+            *reinterpret_cast<vf4*>(lds + lo[u]) = v[u];
           } else {
             float* l = lds + lo[u];
             l[0] = v[u].x; l[1] = v[u].y; l[2] = v[u].z; l[3] = v[u].w;
@@ -299,10 +306,9 @@ __global__ __launch_bounds__(kWave) void mid_kernel(const Params prm) {
   int axis_in = -1;
 #pragma unroll
   for (int k = 0; k < D; ++k) c[k] = 0.0f;
-  if (MODE == kModeStep && (stages & HK_STAGE_SHIFT) && active) {
-    fast_load_coords<D>(prm, g, m, c);
-    axis_in = axis_index(load_scalar(prm.axis, prm.axis_dtype, (size_t)g), D);
-  }
+  RawActions<D> raw;
+  const bool fetch_actions = MODE == kModeStep && (stages & HK_STAGE_SHIFT) && active;
+  if (fetch_actions) fast_fetch_actions<D>(prm, g, m, raw);  // converted after the slab is requested
 
   // ---- 1. the image --------------------------------------------------------------------------------
   if (MODE == kModeGenerate) {
@@ -318,6 +324,7 @@ __global__ __launch_bounds__(kWave) void mid_kernel(const Params prm) {
     mid_copy_slab<true>(lds, const_cast<float*>((const float*)prm.in), prm.in_stride, n_el, S, g0, ngames, lane,
                         vec_in);
   }
+  if (fetch_actions) fast_decode_actions<D>(prm, raw, c, axis_in);
   __syncthreads();
 
   // ---- 2. live rows, exactness guard ------------------------------------------------------------
@@ -483,13 +490,19 @@ inline bool mid_supported(const Params& prm, int dtype) {
 inline int plan_mid(Params& prm) {
   const int w = prm.d == 4 ? 4 : (prm.d == 2 ? 2 : 1);
   const int n = prm.m * prm.d;
-  // room for one running minimum per row behind the image when a 64-game block then still fits
+  // tuning hook (scripts/probe_stages.py): HK_MID_GAMES_PER_WAVE=8|16|32|64
+  static const int forced = [] {
+    const char* e = getenv("HK_MID_GAMES_PER_WAVE");
+    const int v = e ? atoi(e) : 0;
+    return (v == 8 || v == 16 || v == 32 || v == 64) ? v : 0;
+  }();
+  int gpb = forced ? forced : kWave;
+  // room for one running minimum per row behind the image when the block then still fits
   // 64 KiB (>= 2 blocks per CU); big games keep the bare image and use its free tail instead
   int stride = n + prm.m;
-  if ((int64_t)(stride + w + prm.d) * 4 * kWave > 64 * 1024) stride = n;
+  if ((int64_t)(stride + w + prm.d) * 4 * gpb > 64 * 1024) stride = n;
   stride = (stride + w - 1) / w * w;
   if (((stride / w) & 1) == 0) stride += w;
-  int gpb = kWave;
   while (gpb > 1 && (int64_t)(stride + prm.d) * 4 * gpb > kMaxLdsBytes) gpb >>= 1;
   if ((int64_t)(stride + prm.d) * 4 * gpb > kMaxLdsBytes) return HK_ERR_UNSUPPORTED;
   prm.lds_stride = stride;

@@ -151,7 +151,7 @@ def step(points: torch.Tensor, coords=None, axis=None, *, stages: int, flags: in
     res: Dict[str, torch.Tensor] = {}
     for key in want:
         if key in ("done", "prev_done"):
-            res[key] = torch.empty(b, dtype=torch.uint8, device=dev)
+            res[key] = torch.empty(b, dtype=torch.bool, device=dev)  # the kernel stores 0/1 bytes
         elif key == "reward":
             res[key] = torch.empty(b, dtype=torch.float32, device=dev)
         elif key == "num_points":
@@ -167,9 +167,6 @@ def step(points: torch.Tensor, coords=None, axis=None, *, stages: int, flags: in
     s.stages, s.flags = stages, flags
     with torch.cuda.device(dev):
         check(lib().hk_step(C.byref(s), _stream(pts)), "hk_step")
-    for key in ("done", "prev_done"):
-        if key in res:
-            res[key] = res[key].bool()
     if out is None and orig != out_t.dtype:
         out_t = out_t.to(orig)
     res["points"] = out_t
@@ -218,7 +215,7 @@ def _counts(points: torch.Tensor, spec, fn_name: str, out_dtype) -> torch.Tensor
 
 def get_dones(points: torch.Tensor, spec=None) -> torch.Tensor:
     """(#rows with x_0 >= 0) < 2 -- jax/util.py:34-35."""
-    return _counts(points, spec, "hk_get_dones", torch.uint8).bool()
+    return _counts(points, spec, "hk_get_dones", torch.bool)  # 0/1 bytes
 
 
 def get_num_points(points: torch.Tensor, spec=None) -> torch.Tensor:
@@ -342,7 +339,7 @@ def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0
         elif key in ("host_class", "axis"):
             res[key] = torch.empty((steps, b), dtype=torch.int32, device=dev)
         elif key == "done":
-            res[key] = torch.empty((steps, b), dtype=torch.uint8, device=dev)
+            res[key] = torch.empty((steps, b), dtype=torch.bool, device=dev)  # 0/1 bytes
         elif key == "reward":
             res[key] = torch.empty((steps, b), dtype=torch.float32, device=dev)
         elif key == "game_length":
@@ -363,8 +360,6 @@ def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0
     r.workspace, r.workspace_bytes = ws.data_ptr(), ws.numel()
     with torch.cuda.device(dev):
         check(lib().hk_rollout(C.byref(r), _stream(points)), "hk_rollout")
-    if "done" in res:
-        res["done"] = res["done"].bool()
     res["points"] = points
     return res
 
