@@ -510,7 +510,6 @@ bool fast_aligned_t(const Params& prm) {
 // 65 536 games, 64/32/16 games per wave give 50.4/50.7/84.8 us per 20-step rollout and 11.6/12.3/18.5 us
 // per hk_step, so a wave always takes 64 games.
 inline int fast_games_per_block(const Params& prm) {
-  constexpr int kSimds = 256 * 4;  // MI355X
   // tuning hook (scripts/probe_stages.py): HK_FAST_GAMES_PER_WAVE=16|32|64 overrides the heuristic
   static const int forced = [] {
     const char* e = getenv("HK_FAST_GAMES_PER_WAVE");

@@ -131,7 +131,7 @@ __device__ __forceinline__ void c_reposition(float (&q)[C * D], int nmax, unsign
     constexpr int r = decltype(rc)::value;
     if (r >= nmax) return false;
 #pragma unroll
-    for (int k = 0; k < D; ++k) mn[k] = fminf(mn[k], q[r * D + k]);
+    for (int k = 0; k < D; ++k) mn[k] = hk_fmin(mn[k], q[r * D + k]);
     return true;
   });
   float sub[D];
@@ -155,8 +155,8 @@ __device__ __forceinline__ void diff_extrema(const float* a, const float* b, flo
 #pragma unroll
   for (int k = 1; k < D; ++k) {
     const float dk = a[k] - b[k];
-    t = fmaxf(t, dk);
-    u = fminf(u, dk);
+    t = hk_fmax(t, dk);
+    u = hk_fmin(u, dk);
   }
 }
 
@@ -175,8 +175,8 @@ __device__ __forceinline__ void c_newton(float (&q)[C * D], int nmax) {
       if (j >= nmax) return false;
       float t, u;
       diff_extrema<D>(&q[i * D], &q[j * D], t, u);
-      acc[j] = fminf(acc[j], t);
-      acc[i] = fminf(acc[i], (t > 0.0f) ? -u : 1.0f);
+      acc[j] = hk_fmin(acc[j], t);
+      acc[i] = hk_fmin(acc[i], (t > 0.0f) ? -u : 1.0f);
       return true;
     });
     return true;
@@ -202,7 +202,7 @@ __device__ __forceinline__ void c_rescale(float (&q)[C * D], int nmax, unsigned 
     if (r >= nmax) return false;
     const bool live = q[r * D] < INFINITY;
 #pragma unroll
-    for (int k = 0; k < D; ++k) mx = fmaxf(mx, live ? q[r * D + k] : -1.0f);
+    for (int k = 0; k < D; ++k) mx = hk_fmax(mx, live ? q[r * D + k] : -1.0f);
     return true;
   });
   const bool skip = jax_sem ? (mx <= 1e-8f) : (mx < 0.0f);

@@ -59,9 +59,10 @@ constexpr int mid_row_width() { return D == 4 ? 4 : (D == 2 ? 2 : 1); }
 // The loop is rolled (n is a run-time value), so it is batched by hand: kCopyBatch independent
 // requests per lane are issued before the first dependent LDS access, otherwise every iteration would
 // expose a full HBM latency (measured: 273 us instead of ~80 us for the (50,4) slab copy).
-constexpr int kCopyBatch = 16;
+constexpr int kCopyBatchDefault = 16;
+constexpr int kCopyBatchInLoop = 4;  // stores issued inside the rollout loop: keep the loop's register pressure low
 
-template <bool TO_LDS>
+template <bool TO_LDS, int kCopyBatch = kCopyBatchDefault>
 __device__ inline void mid_copy_slab(float* lds, float* glob, int64_t gstride, int n, int S, int64_t g0,
                                      int ngames, int lane, bool vec4) {
   if (vec4) {
@@ -192,7 +193,7 @@ __device__ inline void mid_reposition(float* mine, int n, unsigned flags) {
     float v[D];
     row_load<D>(mine + r * D, v);
 #pragma unroll
-    for (int k = 0; k < D; ++k) mn[k] = fminf(mn[k], v[k]);
+    for (int k = 0; k < D; ++k) mn[k] = hk_fmin(mn[k], v[k]);
   }
   float sub[D];
   bool any = false;
@@ -228,11 +229,11 @@ __device__ inline int mid_newton(float* mine, int n, float* acc_top, Mask64& mas
 #pragma unroll
       for (int k = 1; k < D; ++k) {
         const float dk = qi[k] - qj[k];
-        t = fmaxf(t, dk);
-        u = fminf(u, dk);
+        t = hk_fmax(t, dk);
+        u = hk_fmin(u, dk);
       }
-      acc_top[-j] = fminf(acc_top[-j], t);        // j removed by i iff t <= 0
-      ai = fminf(ai, (t > 0.0f) ? -u : 1.0f);     // i removed by j iff u >= 0 and t > 0
+      acc_top[-j] = hk_fmin(acc_top[-j], t);        // j removed by i iff t <= 0
+      ai = hk_fmin(ai, (t > 0.0f) ? -u : 1.0f);     // i removed by j iff u >= 0 and t > 0
     }
     acc_top[-i] = ai;
   }
@@ -264,7 +265,7 @@ __device__ inline void mid_rescale(float* mine, int n, unsigned flags) {
     float v[D];
     row_load<D>(mine + r * D, v);
 #pragma unroll
-    for (int k = 0; k < D; ++k) mx = fmaxf(mx, v[k]);
+    for (int k = 0; k < D; ++k) mx = hk_fmax(mx, v[k]);
   }
   const bool skip = jax_sem ? (mx <= 1e-8f) : (mx < 0.0f);
   if (skip || mx == 0.0f) return;

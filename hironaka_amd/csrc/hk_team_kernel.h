@@ -1,0 +1,531 @@
+// Team kernel: FOUR lanes per game, for the shapes without a register-resident specialisation
+// (float32, in-place-order semantics, dim 2..6, max_points <= 64 -- BASELINE's (50, 4) above all).
+//
+// Why not one lane per game here.  A (50, 4) game is 800 B; 64 of them fill 51 KiB of LDS, so a CU
+// holds three one-lane-per-game waves -- less than one per SIMD -- and each of them walks its rows
+// through LDS with nothing to hide the latency behind (hk_mid_kernel.h: 392 us per step at 262 144
+// games, 13 % of the HBM roofline).  Giving a game to a QUAD of lanes divides the LDS footprint and the
+// per-wave instruction stream by four (16 games, 13 KiB per wave -> ~11 waves per CU) and puts the
+// rows back in registers:
+//
+//   * live rows are compacted (original order kept); compact row r lives in lane r % 4 of the team,
+//     register slot r / 4 (<= 16 slots = 64 rows).  Rows [n, 4*smax) are +inf holes; smax = the
+//     wave-uniform number of slots in use, every slot loop leaves on it with a scalar branch.
+//   * shift / reposition / rescale work on the registers; column minima / the game maximum are
+//     finished with two DPP quad_perm exchanges (no LDS, no ballots).
+//   * the domination test: the team mirrors its rows into the game's LDS region, then every lane
+//     tests ITS rows i against row j = 0 .. nmax-1 read from LDS (one broadcast ds_read per j for the
+//     whole team), n * n/4 row pairs per lane instead of n^2/2:
+//         t = max_k(P_j - P_i), u = min_k(P_j - P_i);   i is removed  iff  t <= 0 and (u < 0 or j < i)
+//     i.e. P_j <= P_i and (P_j != P_i or j comes first) -- _jax_ops.py:15-73 in one pass; the sign of a
+//     float difference is exact, so this is the reference's `diff >= 0` test.
+//   * the bitmask of live ORIGINAL slots is kept team-uniform; removed rows become holes and the
+//     rows are squeezed again only when the widest game of the wave got narrower.
+//   * publish: pad everywhere, live rows back at their original slots, coalesced slab store.
+//
+// The exactness guard and the whole-wave slow path (exact generic routines on the image, one lane
+// per game) are those of the other kernels.
+#pragma once
+
+#include "hk_mid_kernel.h"
+
+namespace hk {
+
+constexpr int kTeam = 4;
+constexpr int kTeamGames = kWave / kTeam;
+constexpr int kTeamSlots = 16;  // register slots per lane: 4 * 16 = 64 rows
+
+// ---- exchanges inside a quad: DPP quad_perm [1,0,3,2] and [2,3,0,1] ------------------------------------
+template <int CTRL>
+__device__ __forceinline__ int quad_perm_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E;
+
+__device__ __forceinline__ float quad_min(float v) {
+  v = hk_fmin(v, __int_as_float(quad_perm_i<kQuadXor1>(__float_as_int(v))));
+  return hk_fmin(v, __int_as_float(quad_perm_i<kQuadXor2>(__float_as_int(v))));
+}
+__device__ __forceinline__ float quad_max(float v) {
+  v = hk_fmax(v, __int_as_float(quad_perm_i<kQuadXor1>(__float_as_int(v))));
+  return hk_fmax(v, __int_as_float(quad_perm_i<kQuadXor2>(__float_as_int(v))));
+}
+__device__ __forceinline__ uint32_t quad_or(uint32_t v) {
+  v |= (uint32_t)quad_perm_i<kQuadXor1>((int)v);
+  return v | (uint32_t)quad_perm_i<kQuadXor2>((int)v);
+}
+__device__ __forceinline__ Mask64 quad_or64(Mask64 v) {
+  return ((Mask64)quad_or((uint32_t)(v >> 32)) << 32) | quad_or((uint32_t)v);
+}
+
+// ---- rows <-> registers --------------------------------------------------------------------------------
+template <int S_, int W>
+__device__ __forceinline__ int orig_slot(const uint32_t (&orig)[W]) {
+  return (int)((orig[S_ / 4] >> (8 * (S_ % 4))) & 0xFFu);
+}
+
+// Lane `tl` takes the live rows number tl, tl+4, ... (in original order) of `mask`; orig[s] = the row's
+// original slot.  from_compact: the row values sit at their RANK in the region (after a squeeze),
+// otherwise at their original slot (the image).
+// Slots [0, sfill) are written: those past the lane's rows become holes (sfill = the previous smax, so
+// that no stale row survives a squeeze).
+template <int D, int C>
+__device__ __forceinline__ void team_gather(float (&q)[C * D], uint32_t (&orig)[C / 4], const float* mine, Mask64 mask,
+                                            int tl, int sfill, bool from_compact) {
+  Mask64 mk = mask;
+  if (tl > 0) mk &= mk - 1;
+  if (tl > 1) mk &= mk - 1;
+  if (tl > 2) mk &= mk - 1;
+#pragma unroll
+  for (int w = 0; w < C / 4; ++w) orig[w] = 0;
+  unrolled_while<0, C>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (s >= sfill) return false;
+    const bool has = mk != 0;
+    const int o = has ? (__ffsll(mk) - 1) : 0;
+    orig[s / 4] |= (uint32_t)o << (8 * (s % 4));
+    float v[D];
+    row_load<D>(mine + (from_compact ? (has ? kTeam * s + tl : 0) : o) * D, v);
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[s * D + k] = has ? v[k] : INFINITY;
+    mk &= mk - 1;
+    mk &= mk - 1;
+    mk &= mk - 1;
+    mk &= mk - 1;
+    return true;
+  });
+}
+
+// registers -> rows 4s+tl of the region (holes included: they must read as +inf in the test below)
+template <int D, int C>
+__device__ __forceinline__ void team_mirror(const float (&q)[C * D], float* mine, int tl, int smax) {
+  unrolled_while<0, C>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (s >= smax) return false;
+    float v[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) v[k] = q[s * D + k];
+    row_store<D>(mine + (kTeam * s + tl) * D, v);
+    return true;
+  });
+}
+
+// _jax_ops.py:114-123 / _torch_ops.py:113-133
+template <int D, int C>
+__device__ __forceinline__ void team_reposition(float (&q)[C * D], int smax, unsigned flags) {
+  const bool jax_sem = (flags & HK_SEM_MASK) == HK_SEM_JAX;
+  float mn[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) mn[k] = INFINITY;
+  unrolled_while<0, C>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (s >= smax) return false;
+#pragma unroll
+    for (int k = 0; k < D; ++k) mn[k] = hk_fmin(mn[k], q[s * D + k]);
+    return true;
+  });
+  float sub[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    mn[k] = quad_min(mn[k]);
+    sub[k] = (mn[k] < INFINITY && (!jax_sem || mn[k] > 0.0f)) ? mn[k] : 0.0f;
+  }
+  unrolled_while<0, C>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (s >= smax) return false;
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[s * D + k] = q[s * D + k] - sub[k];  // inf - sub = inf: holes stay
+    return true;
+  });
+}
+
+// _jax_ops.py:93-111 / _torch_ops.py:136-146
+template <int D, int C>
+__device__ __forceinline__ void team_rescale(float (&q)[C * D], int smax, unsigned flags) {
+  const bool jax_sem = (flags & HK_SEM_MASK) == HK_SEM_JAX;
+  float mx = -1.0f;
+  unrolled_while<0, C>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (s >= smax) return false;
+    const bool live = q[s * D] < INFINITY;
+#pragma unroll
+    for (int k = 0; k < D; ++k) mx = hk_fmax(mx, live ? q[s * D + k] : -1.0f);
+    return true;
+  });
+  mx = quad_max(mx);
+  const bool skip = jax_sem ? (mx <= 1e-8f) : (mx < 0.0f);
+  const float div = (skip || mx == 0.0f) ? 1.0f : mx;
+  unrolled_while<0, C>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (s >= smax) return false;
+    const bool live = q[s * D] < INFINITY;
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[s * D + k] = live ? q[s * D + k] / div : INFINITY;
+    return true;
+  });
+}
+
+// The pair loop for the first CC slots of a lane, straight-line in the slots: row j of the game comes
+// from the mirror (one broadcast read for the team), every slot tests its row against it.  Slots past
+// the team's rows are +inf holes (their accumulators are never looked at).
+template <int D, int C, int CC>
+__device__ __forceinline__ void team_pairs(const float (&q)[C * D], float (&acc)[C], const float* mine, int tl,
+                                           int nmax) {
+  for (int j = 0; j < nmax; ++j) {  // wave-uniform bound; rows past a team's own count are +inf
+    float pj[D];
+    row_load<D>(mine + j * D, pj);
+    const int jl = j - tl;  // j < 4s + tl  <=>  jl < 4s
+#pragma unroll
+    for (int s = 0; s < CC; ++s) {
+      float t = pj[0] - q[s * D], u = t;
+#pragma unroll
+      for (int k = 1; k < D; ++k) {
+        const float dk = pj[k] - q[s * D + k];
+        t = hk_fmax(t, dk);
+        u = hk_fmin(u, dk);
+      }
+      // t <= 0 implies u <= 0, so "u < 0 or j < i" is the sign of u + (j < i ? -1 : 0)
+      const float e = u + ((jl < kTeam * s) ? -1.0f : 0.0f);
+      acc[s] = hk_fmin(acc[s], (e < 0.0f) ? t : 1.0f);
+    }
+  }
+}
+
+// _jax_ops.py:15-73.  The region must hold the mirror of the team's rows.  Removed rows become holes;
+// returns the team-uniform bitmask of the original slots that were removed.
+//     t = max_k(P_j - P_i), u = min_k(P_j - P_i);   i is removed  iff  t <= 0 and (u < 0 or j < i)
+// The loop body exists for 1, 2, 3, 4, 6, 8, 12 and 16 slots and the wave picks the smallest that
+// covers smax: no branch inside the pair loop, at most a third of the slots idle.
+template <int D, int C>
+__device__ __forceinline__ Mask64 team_newton(float (&q)[C * D], const uint32_t (&orig)[C / 4], const float* mine, int tl,
+                                              int nmax, int smax) {
+  float acc[C];
+#pragma unroll
+  for (int s = 0; s < C; ++s) acc[s] = INFINITY;
+  if (smax <= 1) team_pairs<D, C, 1>(q, acc, mine, tl, nmax);
+  else if (smax <= 2) team_pairs<D, C, 2>(q, acc, mine, tl, nmax);
+  else if (smax <= 3) team_pairs<D, C, 3>(q, acc, mine, tl, nmax);
+  else if (smax <= 4) team_pairs<D, C, 4>(q, acc, mine, tl, nmax);
+  else if (smax <= 6) team_pairs<D, C, 6>(q, acc, mine, tl, nmax);
+  else if (smax <= 8) team_pairs<D, C, 8>(q, acc, mine, tl, nmax);
+  else if (smax <= 12) team_pairs<D, C, 12>(q, acc, mine, tl, nmax);
+  else team_pairs<D, C, 16>(q, acc, mine, tl, nmax);
+  Mask64 dead = 0;
+  unrolled_while<0, C>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (s >= smax) return false;
+    const bool removed = (acc[s] <= 0.0f) && (q[s * D] < INFINITY);
+    dead |= removed ? ((Mask64)1 << orig_slot<s>(orig)) : (Mask64)0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[s * D + k] = removed ? INFINITY : q[s * D + k];
+    return true;
+  });
+  return quad_or64(dead);
+}
+
+// pad everywhere, then the live rows at their original slots
+template <int D, int C>
+__device__ __forceinline__ void team_publish(const float (&q)[C * D], const uint32_t (&orig)[C / 4], float* mine, int m,
+                                             float pad, int tl, int smax, bool active) {
+  float pv[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) pv[k] = pad;
+  if (active)
+    for (int i = tl; i < m; i += kTeam) row_store<D>(mine + i * D, pv);
+  unrolled_while<0, C>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (s >= smax) return false;
+    if (q[s * D] < INFINITY) {
+      float v[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) v[k] = q[s * D + k];
+      row_store<D>(mine + orig_slot<s>(orig) * D, v);
+    }
+    return true;
+  });
+}
+
+// register budget: three waves per SIMD up to dim 4 (<= 168 VGPRs), two beyond
+template <int D, int MODE>
+__global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Params prm) {
+  extern __shared__ __align__(16) unsigned char hk_smem[];
+  float* lds = reinterpret_cast<float*>(hk_smem);
+  constexpr int C = kTeamSlots;
+  const int lane = threadIdx.x;
+  const int tl = lane & (kTeam - 1), tg = lane >> 2;
+  const int m = prm.m, n_el = m * D, S = prm.lds_stride;
+  float* cbuf = lds + kTeamGames * S;  // slow path only: D floats per game
+  const int64_t g0 = (int64_t)blockIdx.x * kTeamGames;
+  const int64_t left = (int64_t)prm.batch - g0;
+  const int ngames = (int)(left < kTeamGames ? left : kTeamGames);
+  const bool active = tg < ngames;
+  const bool leader = active && tl == 0;
+  const int64_t g = g0 + tg;
+  const uint64_t gg = prm.game_offset + (uint64_t)g;
+  float* mine = lds + tg * S;
+  const float pad = (float)prm.pad;
+  const unsigned flags = prm.flags;
+  const unsigned stages = (MODE == kModeGenerate) ? (prm.stages & ~HK_STAGE_SHIFT) : prm.stages;
+  const float fill = ((flags & HK_SEM_MASK) == HK_SEM_TORCH) ? pad : -1.0f;
+  const int nsteps = (MODE == kModeRollout) ? prm.steps : 1;
+  const bool vec_in = (n_el % 4 == 0) && (prm.in_stride % 4 == 0) && prm.in &&
+                      (reinterpret_cast<uintptr_t>(prm.in) % 16 == 0);
+  const bool vec_out = (n_el % 4 == 0) && (prm.out_stride % 4 == 0) &&
+                       (reinterpret_cast<uintptr_t>(prm.out) % 16 == 0);
+  const bool vec_obs = (n_el % 4 == 0) && (reinterpret_cast<uintptr_t>(prm.obs_out) % 16 == 0);
+  PolicyCache pcache;
+
+  float c[D];
+  int axis_in = -1;
+#pragma unroll
+  for (int k = 0; k < D; ++k) c[k] = 0.0f;
+  RawActions<D> raw;
+  const bool fetch_actions = MODE == kModeStep && (stages & HK_STAGE_SHIFT) && active;
+  if (fetch_actions) fast_fetch_actions<D>(prm, g, m, raw);  // converted after the slab is requested
+
+  // ---- 1. the image --------------------------------------------------------------------------------
+  if (MODE == kModeGenerate) {
+    if (active)
+      for (int e = tl * 4; e < n_el; e += 4 * kTeam) {
+        const U4 r = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), (uint32_t)(e >> 2), kStreamGenerate,
+                                prm.seed);
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+        for (int qd = 0; qd < 4 && e + qd < n_el; ++qd)
+          mine[e + qd] = (float)mulhi32(w[qd], (uint32_t)prm.max_value);
+      }
+  } else {
+    mid_copy_slab<true>(lds, const_cast<float*>((const float*)prm.in), prm.in_stride, n_el, S, g0, ngames, lane,
+                        vec_in);
+  }
+  if (fetch_actions) fast_decode_actions<D>(prm, raw, c, axis_in);
+  __syncthreads();
+
+  // ---- 2. live rows, exactness guard (each lane scans every fourth row of its game) -----------------
+  Mask64 part = 0;
+  bool ok = true;
+  if (active)
+    for (int i = tl; i < m; i += kTeam) {
+      float v[D];
+      row_load<D>(mine + i * D, v);
+      bool ge = true, fl = true;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        ge &= (__float_as_uint(v[k]) < 0x7F800000u);  // [+0, +inf)
+        fl &= (v[k] == fill);
+      }
+      ok &= (ge | fl);
+      part |= ge ? ((Mask64)1 << i) : (Mask64)0;
+    }
+  Mask64 gmask = quad_or64(part);
+  ok = quad_or(ok ? 0u : 1u) == 0u;
+  int np = __popcll(gmask);
+  int nmax = wave_max(np, m);
+  int smax = (nmax + kTeam - 1) / kTeam;
+  const bool exact = (fill == pad) && __all(ok);
+
+  if (!exact) {
+    // ---- slow path (whole wave): the exact generic routines on the image, one lane per game ------
+    float* cs = cbuf + tg * D;
+    np = leader ? num_points<float>(mine, m, D) : 2;
+    int length = (np < 2) ? 0 : -1;
+    if (MODE == kModeRollout && prm.count_ws) {
+      const unsigned long long b0 = __ballot(leader && np < 2);
+      if (lane == 0) prm.count_ws[blockIdx.x] = (uint32_t)__popcll(b0);
+    }
+    for (int t = 0; t < nsteps; ++t) {
+      int axis = -1, cls = 0;
+      if (MODE == kModeRollout) {
+        if (prm.obs_out) {
+          __syncthreads();
+          mid_copy_slab<false>(lds, (float*)prm.obs_out + (int64_t)t * prm.batch * n_el, (int64_t)n_el, n_el, S,
+                               g0, ngames, lane, vec_obs);
+          __syncthreads();
+        }
+        uint32_t mask;
+        fast_policy<D>(prm, gg, prm.step_offset + (uint32_t)t, pcache, cls, axis, mask);
+        if (leader)
+          for (int k = 0; k < D; ++k) cs[k] = (float)((mask >> k) & 1u);
+      } else if (MODE == kModeStep && (stages & HK_STAGE_SHIFT) && leader) {
+        load_coords<float>(prm, g, cs);
+        axis = axis_in;
+      }
+      const bool prev_done = np < 2;
+      if (leader) stages_game<float>(mine, m, prm.d, cs, axis, pad, stages, flags);
+      np = leader ? num_points<float>(mine, m, prm.d) : 2;
+      const bool done = np < 2;
+      if (done && length < 0) length = t + 1;
+      if (MODE == kModeRollout) {
+        if (leader) {
+          const int64_t at = (int64_t)t * prm.batch + g;
+          if (prm.r_host_class_out) prm.r_host_class_out[at] = cls;
+          if (prm.r_axis_out) prm.r_axis_out[at] = axis;
+          if (prm.r_done_out) prm.r_done_out[at] = done;
+          if (prm.r_reward_out) prm.r_reward_out[at] = prm.reward_sign * (float)(done && !prev_done);
+        }
+        if (prm.count_ws) {
+          const unsigned long long bd = __ballot(leader && done);
+          if (lane == 0) prm.count_ws[(size_t)(t + 1) * gridDim.x + blockIdx.x] = (uint32_t)__popcll(bd);
+        }
+      } else if (MODE == kModeStep && leader) {
+        if (prm.done_out) prm.done_out[g] = done;
+        if (prm.prev_done_out) prm.prev_done_out[g] = prev_done;
+        if (prm.reward_out) prm.reward_out[g] = prm.reward_sign * (float)(done && !prev_done);
+        if (prm.num_points_out) prm.num_points_out[g] = np;
+      }
+    }
+    if (MODE == kModeRollout && leader && prm.game_length_out) prm.game_length_out[g] = length;
+    __syncthreads();
+    mid_copy_slab<false>(lds, (float*)prm.out, prm.out_stride, n_el, S, g0, ngames, lane, vec_out);
+    return;
+  }
+
+  // ---- 3. the live rows into registers ---------------------------------------------------------------
+  float q[C * D];
+  uint32_t orig[C / 4];  // original slot of each register row, one byte each
+#pragma unroll
+  for (int e = 0; e < C * D; ++e) q[e] = INFINITY;  // slots past smax are holes in the pair loop
+  if (!active) {  // teams past the batch: an empty, harmless game
+    gmask = 0;
+    np = 2;  // never "done", never counted
+  }
+  team_gather<D, C>(q, orig, mine, gmask, tl, smax, false);
+  int length = (np < 2) ? 0 : -1;
+  if (MODE == kModeRollout && prm.count_ws) {
+    const unsigned long long b0 = __ballot(leader && np < 2);
+    if (lane == 0) prm.count_ws[blockIdx.x] = (uint32_t)__popcll(b0);
+  }
+
+  // ---- 4. the transitions --------------------------------------------------------------------------
+  for (int t = 0; t < nsteps; ++t) {
+    int axis = -1, cls = 0;
+    if (MODE == kModeRollout) {
+      if (prm.obs_out) {  // state before the step: rebuild the image, store it coalesced
+        __syncthreads();
+        team_publish<D, C>(q, orig, mine, m, pad, tl, smax, active);
+        __syncthreads();
+        mid_copy_slab<false, kCopyBatchInLoop>(lds, (float*)prm.obs_out + (int64_t)t * prm.batch * n_el,
+                                               (int64_t)n_el, n_el, S, g0, ngames, lane, vec_obs);
+        __syncthreads();
+      }
+      uint32_t mask;
+      fast_policy<D>(prm, gg, prm.step_offset + (uint32_t)t, pcache, cls, axis, mask);
+#pragma unroll
+      for (int k = 0; k < D; ++k) c[k] = (float)((mask >> k) & 1u);
+    } else if (MODE == kModeStep) {
+      axis = axis_in;
+    }
+    const bool prev_done = np < 2;
+
+    if (stages & HK_STAGE_SHIFT) c_shift<C, D>(q, smax, c, axis, np, flags);
+    if (stages & HK_STAGE_REPOSITION) team_reposition<D, C>(q, smax, flags);
+    if (stages & HK_STAGE_NEWTON) {
+      team_mirror<D, C>(q, mine, tl, smax);
+      __syncthreads();
+      const Mask64 dead = team_newton<D, C>(q, orig, mine, tl, nmax, smax);
+      gmask &= ~dead;
+      if (active) np = __popcll(gmask);
+    }
+    if (stages & HK_STAGE_RESCALE) team_rescale<D, C>(q, smax, flags);
+
+    const bool done = np < 2;
+    if (done && length < 0) length = t + 1;
+    if (MODE == kModeRollout) {
+      if (leader) {
+        const int64_t at = (int64_t)t * prm.batch + g;
+        if (prm.r_host_class_out) prm.r_host_class_out[at] = cls;
+        if (prm.r_axis_out) prm.r_axis_out[at] = axis;
+        if (prm.r_done_out) prm.r_done_out[at] = done;
+        if (prm.r_reward_out) prm.r_reward_out[at] = prm.reward_sign * (float)(done && !prev_done);
+      }
+      if (prm.count_ws) {
+        const unsigned long long bd = __ballot(leader && done);
+        if (lane == 0) prm.count_ws[(size_t)(t + 1) * gridDim.x + blockIdx.x] = (uint32_t)__popcll(bd);
+      }
+      // squeeze when the widest game of the wave got narrower: live rows to their new ranks in the
+      // region, then every lane takes back rows 4s+tl
+      if (t + 1 < nsteps && !__any(active && np >= nmax)) {
+        __syncthreads();
+        unrolled_while<0, C>([&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          if (s >= smax) return false;
+          if (q[s * D] < INFINITY) {
+            const int rank = __popcll(gmask & (((Mask64)1 << orig_slot<s>(orig)) - 1));
+            float v[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) v[k] = q[s * D + k];
+            row_store<D>(mine + rank * D, v);
+          }
+          return true;
+        });
+        __syncthreads();
+        nmax = wave_max(active ? np : 0, nmax - 1);
+        const int sprev = smax;
+        smax = (nmax + kTeam - 1) / kTeam;
+        team_gather<D, C>(q, orig, mine, gmask, tl, sprev, true);
+      }
+    } else if (MODE == kModeStep && leader) {
+      if (prm.done_out) prm.done_out[g] = done;
+      if (prm.prev_done_out) prm.prev_done_out[g] = prev_done;
+      if (prm.reward_out) prm.reward_out[g] = prm.reward_sign * (float)(done && !prev_done);
+      if (prm.num_points_out) prm.num_points_out[g] = np;
+    }
+  }
+  if (MODE == kModeRollout && leader && prm.game_length_out) prm.game_length_out[g] = length;
+
+  // ---- 5. publish ----------------------------------------------------------------------------------
+  __syncthreads();
+  team_publish<D, C>(q, orig, mine, m, pad, tl, smax, active);
+  __syncthreads();
+  mid_copy_slab<false>(lds, (float*)prm.out, prm.out_stride, n_el, S, g0, ngames, lane, vec_out);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+inline bool team_supported(const Params& prm, int dtype) {
+  if (prm.flags & HK_FLAG_FORCE_LDS_ROWS) return false;
+  return mid_supported(prm, dtype);
+}
+
+// LDS geometry: 16 regions of `stride` floats (>= the rows rounded up to a multiple of 4, stride / row
+// width odd so that the 16 teams' broadcast reads fall on different banks) + D floats per game of
+// slow-path scratch
+inline int plan_team(Params& prm) {
+  const int w = prm.d == 4 ? 4 : (prm.d == 2 ? 2 : 1);
+  int stride = ((prm.m + kTeam - 1) / kTeam) * kTeam * prm.d;
+  stride = (stride + w - 1) / w * w;
+  if (((stride / w) & 1) == 0) stride += w;
+  if ((int64_t)(stride + prm.d) * 4 * kTeamGames > kMaxLdsBytes) return HK_ERR_UNSUPPORTED;
+  prm.lds_stride = stride;
+  prm.games_per_block = kTeamGames;
+  return HK_OK;
+}
+
+template <int D, int MODE>
+int launch_team_t(const Params& prm, hipStream_t stream) {
+  const size_t lds = (size_t)(prm.lds_stride + prm.d) * kTeamGames * sizeof(float);
+  const unsigned grid = (unsigned)(((int64_t)prm.batch + kTeamGames - 1) / kTeamGames);
+  launch_prepare();
+  hipLaunchKernelGGL((team_kernel<D, MODE>), dim3(grid), dim3(kWave), lds, stream, prm);
+  return launch_status();
+}
+
+template <int D>
+int launch_team_d(const Params& prm, hipStream_t stream) {
+  if (prm.mode == kModeStep) return launch_team_t<D, kModeStep>(prm, stream);
+  if (prm.mode == kModeRollout) return launch_team_t<D, kModeRollout>(prm, stream);
+  return launch_team_t<D, kModeGenerate>(prm, stream);
+}
+
+inline int launch_team(Params& prm, hipStream_t stream) {
+  const int st = plan_team(prm);
+  if (st != HK_OK) return st;
+  switch (prm.d) {
+    case 2: return launch_team_d<2>(prm, stream);
+    case 3: return launch_team_d<3>(prm, stream);
+    case 4: return launch_team_d<4>(prm, stream);
+    case 5: return launch_team_d<5>(prm, stream);
+    case 6: return launch_team_d<6>(prm, stream);
+  }
+  return HK_ERR_UNSUPPORTED;
+}
+
+}  // namespace hk

@@ -260,12 +260,48 @@ def test_random_vs_oracle_lds_rows_on_fast_specs(spec):
 
 
 @pytest.mark.parametrize("spec", MID_SPECS)
-def test_random_vs_oracle_mid_specs(spec):
-    """f32 shapes without a register specialisation run on the LDS-rows kernel (hk_mid_kernel.h)"""
+@pytest.mark.parametrize("lds_rows", [False, True])
+def test_random_vs_oracle_mid_specs(spec, lds_rows):
+    """f32 shapes without a register specialisation run on the team kernel (four lanes per game,
+    hk_team_kernel.h) or, forced, on the one-lane-per-game LDS-rows kernel (hk_mid_kernel.h)"""
     m, d = spec
     assert not ops.has_fast_path(m, d)
     rng = np.random.default_rng(31 * m + d)
-    _check_all_ops(rng, m, d, np.float32, force_generic=False, b=70 if m < 50 else 67)
+    _check_all_ops(rng, m, d, np.float32, force_generic=False, b=70 if m < 50 else 67, force_lds_rows=lds_rows)
+
+
+@pytest.mark.parametrize("spec", [(50, 4), (33, 4), (64, 3), (12, 6), (7, 3), (2, 2)])
+def test_team_kernel_rollout_generate_match_other_kernels(spec):
+    """fused rollouts (with the squeeze of the register rows), per-step observations and the generator on
+    the team kernel against the LDS-rows and generic kernels and the C oracle"""
+    m, d = spec
+    b = 1000
+    P = ops.generate_points(b, m, d, 20, seed=5)
+    assert torch.equal(P, ops.generate_points(b, m, d, 20, seed=5, flags=A.HK_FLAG_FORCE_LDS_ROWS))
+    assert torch.equal(P, ops.generate_points(b, m, d, 20, seed=5, flags=A.HK_FLAG_FORCE_GENERIC))
+    assert np.array_equal(host(P), CO.generate_points(b, m, d, 20, 5))
+    rec = ("obs", "host_class", "axis", "done", "reward", "game_length")
+    outs = []
+    for fl in (0, A.HK_FLAG_FORCE_LDS_ROWS, A.HK_FLAG_FORCE_GENERIC):
+        Q = P.clone()
+        r = ops.rollout(Q, 12, 9, record=rec, flags=fl)
+        outs.append((Q, r))
+    for Q, r in outs[1:]:
+        assert torch.equal(outs[0][0], Q)
+        for k in rec + ("done_count",):
+            assert torch.equal(outs[0][1][k], r[k]), k
+    want, wrec = CO.rollout(host(P), 12, 9, record=True)
+    assert np.array_equal(host(outs[0][0]), want)
+    assert np.array_equal(host(outs[0][1]["obs"]), wrec["obs"])
+    assert np.array_equal(host(outs[0][1]["done_count"]), wrec["done_count"])
+    # ragged tail: the last wave holds fewer than 16 games
+    for bb in (1, 15, 17, 63):
+        Pb = P[:bb].contiguous()
+        cls = torch.randint(0, 2 ** d - d - 1, (bb,), device="cuda", dtype=torch.int64)
+        ax = torch.randint(0, d, (bb,), device="cuda", dtype=torch.int64)
+        got = ops.step(Pb, cls, ax, stages=15, want=("done", "reward"))
+        ref = CO.step(host(Pb), host(cls), host(ax), stages=15)
+        assert np.array_equal(host(got["points"]), ref["points"]) and np.array_equal(host(got["done"]), ref["done"])
 
 
 @pytest.mark.parametrize("spec", GENERIC_SPECS + [(20, 3), (10, 3)])
