@@ -37,7 +37,7 @@ HK_FLAG_AXIS_NOOP_IF_INVALID = 4
 HK_FLAG_IGNORE_ENDED = 8
 HK_FLAG_COMPACT_SORTED = 16
 HK_FLAG_FORCE_GENERIC = 32
-HK_FLAG_FORCE_LDS_ROWS = 64
+HK_FLAG_FORCE_TEAM = 64
 
 # fused policies
 HK_HOST_RANDOM, HK_HOST_ALL_COORD, HK_HOST_ZEILLINGER = 0, 1, 2

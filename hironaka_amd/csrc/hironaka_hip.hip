@@ -2,7 +2,6 @@
 // and launch.  No allocation, no synchronisation, no exceptions; every entry point returns a
 // status code.  gfx950 only.
 #include "hk_fast_kernel.h"
-#include "hk_mid_kernel.h"
 #include "hk_team_kernel.h"
 #include "hk_generic_kernel.h"
 
@@ -58,17 +57,13 @@ int launch_generic(Params& prm, int dtype, hipStream_t stream) {
   return dtype == HK_F32 ? launch_generic_t<float>(prm, stream) : launch_generic_t<double>(prm, stream);
 }
 
-// kernel selection: register-resident specialisation -> team kernel (f32, dim 2..6, <= 64 rows; the
-// one-lane-per-game LDS-rows kernel only on HK_FLAG_FORCE_LDS_ROWS) -> generic kernel (anything else: f64, list semantics, sorted output, Zeillinger, feature sort)
+// kernel selection: register-resident specialisation -> team kernel (f32, dim 2..6, <= 64 rows; also the
+// specialised shapes on HK_FLAG_FORCE_TEAM) -> generic kernel (anything else: f64, list semantics, sorted output, Zeillinger, feature sort)
 int launch(Params& prm, int dtype, hipStream_t stream) {
   if (prm.batch == 0) return HK_OK;
   if (fast_supported(prm, dtype)) return launch_fast(prm, stream);
   if (team_supported(prm, dtype)) {
     const int st = launch_team(prm, stream);
-    if (st != HK_ERR_UNSUPPORTED) return st;
-  }
-  if (mid_supported(prm, dtype)) {
-    const int st = launch_mid(prm, stream);
     if (st != HK_ERR_UNSUPPORTED) return st;
   }
   return launch_generic(prm, dtype, stream);
@@ -82,8 +77,6 @@ int64_t planned_grid(Params prm, int dtype) {
     return ((int64_t)prm.batch + gpb - 1) / gpb;
   }
   if (team_supported(prm, dtype) && plan_team(prm) == HK_OK)
-    return ((int64_t)prm.batch + prm.games_per_block - 1) / prm.games_per_block;
-  if (mid_supported(prm, dtype) && plan_mid(prm) == HK_OK)
     return ((int64_t)prm.batch + prm.games_per_block - 1) / prm.games_per_block;
   if (plan_generic(prm, dtype) != HK_OK) return 0;
   return ((int64_t)prm.batch + prm.games_per_block - 1) / prm.games_per_block;

@@ -538,7 +538,7 @@ int launch_fast_t(Params prm, hipStream_t stream) {
 inline bool fast_supported(const Params& prm, int dtype) {
   if (dtype != HK_F32) return false;
   if ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)) return false;
-  if (prm.flags & (HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_LDS_ROWS)) return false;
+  if (prm.flags & (HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_TEAM)) return false;
   if (prm.stages & kStageFeatureSort) return false;
   if (prm.mode == kModeZeillinger) return false;
   if (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER) return false;

@@ -3,8 +3,8 @@
 //
 // Why not one lane per game here.  A (50, 4) game is 800 B; 64 of them fill 51 KiB of LDS, so a CU
 // holds three one-lane-per-game waves -- less than one per SIMD -- and each of them walks its rows
-// through LDS with nothing to hide the latency behind (hk_mid_kernel.h: 392 us per step at 262 144
-// games, 13 % of the HBM roofline).  Giving a game to a QUAD of lanes divides the LDS footprint and the
+// through LDS with nothing to hide the latency behind (the first version of this path did exactly that:
+// 392 us per step at 262 144 games, 13 % of the HBM roofline; this kernel: 129 us, 41 %).  Giving a game to a QUAD of lanes divides the LDS footprint and the
 // per-wave instruction stream by four (16 games, 13 KiB per wave -> ~11 waves per CU) and puts the
 // rows back in registers:
 //
@@ -27,7 +27,7 @@
 // per game) are those of the other kernels.
 #pragma once
 
-#include "hk_mid_kernel.h"
+#include "hk_rows_io.h"
 
 namespace hk {
 
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
           mine[e + qd] = (float)mulhi32(w[qd], (uint32_t)prm.max_value);
       }
   } else {
-    mid_copy_slab<true>(lds, const_cast<float*>((const float*)prm.in), prm.in_stride, n_el, S, g0, ngames, lane,
+    rows_copy_slab<true>(lds, const_cast<float*>((const float*)prm.in), prm.in_stride, n_el, S, g0, ngames, lane,
                         vec_in);
   }
   if (fetch_actions) fast_decode_actions<D>(prm, raw, c, axis_in);
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
       if (MODE == kModeRollout) {
         if (prm.obs_out) {
           __syncthreads();
-          mid_copy_slab<false>(lds, (float*)prm.obs_out + (int64_t)t * prm.batch * n_el, (int64_t)n_el, n_el, S,
+          rows_copy_slab<false>(lds, (float*)prm.obs_out + (int64_t)t * prm.batch * n_el, (int64_t)n_el, n_el, S,
                                g0, ngames, lane, vec_obs);
           __syncthreads();
         }
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
     }
     if (MODE == kModeRollout && leader && prm.game_length_out) prm.game_length_out[g] = length;
     __syncthreads();
-    mid_copy_slab<false>(lds, (float*)prm.out, prm.out_stride, n_el, S, g0, ngames, lane, vec_out);
+    rows_copy_slab<false>(lds, (float*)prm.out, prm.out_stride, n_el, S, g0, ngames, lane, vec_out);
     return;
   }
 
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
         __syncthreads();
         team_publish<D, C>(q, orig, mine, m, pad, tl, smax, active);
         __syncthreads();
-        mid_copy_slab<false, kCopyBatchInLoop>(lds, (float*)prm.obs_out + (int64_t)t * prm.batch * n_el,
+        rows_copy_slab<false, kCopyBatchInLoop>(lds, (float*)prm.obs_out + (int64_t)t * prm.batch * n_el,
                                                (int64_t)n_el, n_el, S, g0, ngames, lane, vec_obs);
         __syncthreads();
       }
@@ -476,13 +476,20 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
   __syncthreads();
   team_publish<D, C>(q, orig, mine, m, pad, tl, smax, active);
   __syncthreads();
-  mid_copy_slab<false>(lds, (float*)prm.out, prm.out_stride, n_el, S, g0, ngames, lane, vec_out);
+  rows_copy_slab<false>(lds, (float*)prm.out, prm.out_stride, n_el, S, g0, ngames, lane, vec_out);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
+// HK_FLAG_FORCE_TEAM puts the shapes that have a register-resident specialisation on this kernel too
 inline bool team_supported(const Params& prm, int dtype) {
-  if (prm.flags & HK_FLAG_FORCE_LDS_ROWS) return false;
-  return mid_supported(prm, dtype);
+  if (dtype != HK_F32) return false;
+  if ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)) return false;
+  if (prm.flags & HK_FLAG_FORCE_GENERIC) return false;
+  if (prm.stages & kStageFeatureSort) return false;
+  if (prm.mode == kModeZeillinger) return false;
+  if (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER) return false;
+  if (prm.d < 2 || prm.d > 6 || prm.m > kTeam * kTeamSlots) return false;
+  return true;
 }
 
 // LDS geometry: 16 regions of `stride` floats (>= the rows rounded up to a multiple of 4, stride / row

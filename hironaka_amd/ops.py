@@ -25,7 +25,7 @@ ALL_STAGES = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON | A.HK
 
 
 def make_flags(sem: str = "jax", noop_if_invalid: bool = False, ignore_ended: bool = False,
-               compact_sorted: bool = False, force_generic: bool = False, force_lds_rows: bool = False) -> int:
+               compact_sorted: bool = False, force_generic: bool = False, force_team: bool = False) -> int:
     if sem not in A.SEMANTICS:
         raise ValueError(f"sem must be one of {sorted(A.SEMANTICS)}. Got {sem}.")
     f = A.SEMANTICS[sem]
@@ -37,8 +37,8 @@ def make_flags(sem: str = "jax", noop_if_invalid: bool = False, ignore_ended: bo
         f |= A.HK_FLAG_COMPACT_SORTED
     if force_generic:
         f |= A.HK_FLAG_FORCE_GENERIC
-    if force_lds_rows:
-        f |= A.HK_FLAG_FORCE_LDS_ROWS
+    if force_team:
+        f |= A.HK_FLAG_FORCE_TEAM
     return f
 
 

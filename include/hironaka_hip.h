@@ -90,8 +90,8 @@ extern "C" {
 #define HK_FLAG_COMPACT_SORTED 16u      /* Newton output sorted descending-lex + compacted
                                            (list semantics, _list_ops.py:25-41)            */
 #define HK_FLAG_FORCE_GENERIC 32u       /* testing: bypass the specialised kernels          */
-#define HK_FLAG_FORCE_LDS_ROWS 64u      /* testing: bypass only the register-resident
-                                           specialisations (use the LDS-rows kernel)        */
+#define HK_FLAG_FORCE_TEAM 64u          /* testing: bypass only the register-resident
+                                           specialisations (use the four-lanes-per-game kernel) */
 
 /* ---- fixed policies fused into hk_rollout (jax/players.py) ----------------------------- */
 #define HK_HOST_RANDOM 0    /* players.py:28-39   uniform class id                          */

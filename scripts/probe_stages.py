@@ -35,12 +35,12 @@ def main():
     print(f"batch {b} spec ({m},{d}) state {P.numel()*4/1e6:.1f} MB")
     print("d2d copy            %.2f us" % timeit(lambda: Q.copy_(P)))
     for name, st in (("none", 0), ("shift", 1), ("reposition", 2), ("newton", 4), ("shift+repos+newton", 7), ("all4", 15)):
-        for kind, fl in (("default", 0), ("ldsrows", A.HK_FLAG_FORCE_LDS_ROWS), ("generic", A.HK_FLAG_FORCE_GENERIC)):
+        for kind, fl in (("default", 0), ("team", A.HK_FLAG_FORCE_TEAM), ("generic", A.HK_FLAG_FORCE_GENERIC)):
             t = timeit(lambda: ops.step(P, cls, ax, stages=st, flags=fl, out=Q))
             print(f"step stages={name:20s} {kind} {t:8.2f} us")
     S = P.clone()
     dcs = {T: torch.zeros(T + 1, dtype=torch.int64, device="cuda") for T in (1, 2, 5, 20)}
-    for kind, fl in (("default", 0), ("ldsrows", A.HK_FLAG_FORCE_LDS_ROWS)):
+    for kind, fl in (("default", 0), ("team", A.HK_FLAG_FORCE_TEAM)):
         for T in (1, 2, 5, 20):
             def f():
                 ops.rollout(S, T, 7, done_count=dcs[T], initial=P, flags=fl)

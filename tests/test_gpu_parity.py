@@ -16,7 +16,7 @@ from oracle import np_oracle as NO
 pytestmark = pytest.mark.gpu
 
 FAST_SPECS = [(4, 3), (5, 3), (10, 3), (16, 3), (20, 3), (8, 4), (20, 4)]   # register-resident kernels
-MID_SPECS = [(50, 4), (7, 3), (5, 2), (6, 5), (12, 6), (3, 3), (64, 3), (33, 4), (2, 2)]  # LDS-rows kernel (f32)
+TEAM_SPECS = [(50, 4), (7, 3), (5, 2), (6, 5), (12, 6), (3, 3), (64, 3), (33, 4), (2, 2)]  # team kernel (f32, four lanes per game)
 GENERIC_SPECS = [(7, 3), (5, 2), (6, 5), (12, 6), (3, 3), (64, 3), (70, 3), (9, 7)]
 
 
@@ -195,7 +195,7 @@ def test_live_config1_trajectory(live_list, scale):
 # seeded random inputs against the C oracle: every mode, both kernel families
 # ------------------------------------------------------------------------------------------
 
-def _check_all_ops(rng, m, d, dtype, force_generic, b=97, force_lds_rows=False):
+def _check_all_ops(rng, m, d, dtype, force_generic, b=97, force_team=False):
     tdt = torch.float32 if dtype == np.float32 else torch.float64
     for sem in ("jax", "torch", "list"):
         for pad in (-1.0, -1e-8, -2.5):
@@ -206,7 +206,7 @@ def _check_all_ops(rng, m, d, dtype, force_generic, b=97, force_lds_rows=False):
             if d > 1:
                 p[4, 0, 0] = -0.5  # a mixed-sign row
             P = dev(p)
-            kw = dict(sem=sem, padding_value=pad, force_generic=force_generic, force_lds_rows=force_lds_rows)
+            kw = dict(sem=sem, padding_value=pad, force_generic=force_generic, force_team=force_team)
             for compact in (False, True):
                 got = host(ops.get_newton_polytope(P, compact_sorted=compact, **kw))
                 assert np.array_equal(got, CO.get_newton_polytope(p, pad, sem=sem, compact_sorted=compact)), (sem, pad, compact)
@@ -219,7 +219,7 @@ def _check_all_ops(rng, m, d, dtype, force_generic, b=97, force_lds_rows=False):
                     want = CO.shift(p, cls, ax, pad, sem=sem, noop_if_invalid=noop, ignore_ended=ign)
                     got = ops.shift(P, dev(cls), dev(ax), noop_if_invalid=noop, ignore_ended=ign, **kw)
                     assert np.array_equal(host(got), want), (sem, pad, noop, ign)
-            fl = ops.make_flags(sem, force_generic=force_generic, force_lds_rows=force_lds_rows)
+            fl = ops.make_flags(sem, force_generic=force_generic, force_team=force_team)
             for stages in (A.HK_STAGE_SHIFT | A.HK_STAGE_NEWTON, 7, 15):
                 want = CO.step(p, cls, ax, stages=stages, flags=CO.flags_of(sem=sem), padding_value=pad, reward_sign=-1.0)
                 got = ops.step(P, dev(cls), dev(ax).to(tdt), stages=stages, flags=fl, padding_value=pad,
@@ -241,48 +241,47 @@ def test_random_vs_oracle_fast_specs(spec):
 
 
 @pytest.mark.parametrize("spec", [(20, 3), (10, 3), (8, 4), (4, 3)])
-def test_random_vs_oracle_lds_rows_on_fast_specs(spec):
-    """the LDS-rows kernel forced onto shapes that normally run register-resident"""
+def test_random_vs_oracle_team_kernel_on_fast_specs(spec):
+    """the team kernel forced onto shapes that normally run register-resident"""
     m, d = spec
     rng = np.random.default_rng(17 * m + d)
-    _check_all_ops(rng, m, d, np.float32, force_generic=False, b=97, force_lds_rows=True)
+    _check_all_ops(rng, m, d, np.float32, force_generic=False, b=97, force_team=True)
     P = ops.generate_points(3000, m, d, 20, seed=2)
     cls = torch.randint(0, 2 ** d - d - 1, (3000,), device="cuda", dtype=torch.int32)
     ax = torch.randint(0, d, (3000,), device="cuda", dtype=torch.int32)
     a = ops.step(P, cls, ax, stages=7)["points"]
-    assert torch.equal(a, ops.step(P, cls, ax, stages=7, flags=A.HK_FLAG_FORCE_LDS_ROWS)["points"])
+    assert torch.equal(a, ops.step(P, cls, ax, stages=7, flags=A.HK_FLAG_FORCE_TEAM)["points"])
     Q1, Q2 = P.clone(), P.clone()
     r1 = ops.rollout(Q1, 15, 4, record=("axis", "done"))
-    r2 = ops.rollout(Q2, 15, 4, record=("axis", "done"), flags=A.HK_FLAG_FORCE_LDS_ROWS)
+    r2 = ops.rollout(Q2, 15, 4, record=("axis", "done"), flags=A.HK_FLAG_FORCE_TEAM)
     assert torch.equal(Q1, Q2) and torch.equal(r1["done"], r2["done"]) and torch.equal(r1["done_count"], r2["done_count"])
     g1 = ops.generate_points(500, m, d, 20, seed=8)
-    assert torch.equal(g1, ops.generate_points(500, m, d, 20, seed=8, flags=A.HK_FLAG_FORCE_LDS_ROWS))
+    assert torch.equal(g1, ops.generate_points(500, m, d, 20, seed=8, flags=A.HK_FLAG_FORCE_TEAM))
 
 
-@pytest.mark.parametrize("spec", MID_SPECS)
-@pytest.mark.parametrize("lds_rows", [False, True])
-def test_random_vs_oracle_mid_specs(spec, lds_rows):
+@pytest.mark.parametrize("spec", TEAM_SPECS)
+def test_random_vs_oracle_team_specs(spec):
     """f32 shapes without a register specialisation run on the team kernel (four lanes per game,
-    hk_team_kernel.h) or, forced, on the one-lane-per-game LDS-rows kernel (hk_mid_kernel.h)"""
+    hk_team_kernel.h)"""
     m, d = spec
     assert not ops.has_fast_path(m, d)
     rng = np.random.default_rng(31 * m + d)
-    _check_all_ops(rng, m, d, np.float32, force_generic=False, b=70 if m < 50 else 67, force_lds_rows=lds_rows)
+    _check_all_ops(rng, m, d, np.float32, force_generic=False, b=70 if m < 50 else 67)
 
 
 @pytest.mark.parametrize("spec", [(50, 4), (33, 4), (64, 3), (12, 6), (7, 3), (2, 2)])
 def test_team_kernel_rollout_generate_match_other_kernels(spec):
     """fused rollouts (with the squeeze of the register rows), per-step observations and the generator on
-    the team kernel against the LDS-rows and generic kernels and the C oracle"""
+    the team kernel against the generic kernel and the C oracle"""
     m, d = spec
     b = 1000
     P = ops.generate_points(b, m, d, 20, seed=5)
-    assert torch.equal(P, ops.generate_points(b, m, d, 20, seed=5, flags=A.HK_FLAG_FORCE_LDS_ROWS))
+    assert torch.equal(P, ops.generate_points(b, m, d, 20, seed=5, flags=A.HK_FLAG_FORCE_TEAM))
     assert torch.equal(P, ops.generate_points(b, m, d, 20, seed=5, flags=A.HK_FLAG_FORCE_GENERIC))
     assert np.array_equal(host(P), CO.generate_points(b, m, d, 20, 5))
     rec = ("obs", "host_class", "axis", "done", "reward", "game_length")
     outs = []
-    for fl in (0, A.HK_FLAG_FORCE_LDS_ROWS, A.HK_FLAG_FORCE_GENERIC):
+    for fl in (0, A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC):
         Q = P.clone()
         r = ops.rollout(Q, 12, 9, record=rec, flags=fl)
         outs.append((Q, r))
@@ -471,7 +470,7 @@ def test_error_behaviour():
 def test_ragged_batch_sizes(b):
     """batches that do not fill the last wave (or even one wave), every kernel family, step + rollout +
     generate; also checks nothing is written past the batch (guard rows after the tensors)."""
-    for (m, d), flag_sets in (((20, 3), (0, A.HK_FLAG_FORCE_LDS_ROWS, A.HK_FLAG_FORCE_GENERIC)),
+    for (m, d), flag_sets in (((20, 3), (0, A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC)),
                               ((50, 4), (0, A.HK_FLAG_FORCE_GENERIC)), ((7, 5), (0, A.HK_FLAG_FORCE_GENERIC))):
         p0 = CO.generate_points(b, m, d, 20, 3, game_offset=9)
         rng = np.random.default_rng(b)
@@ -536,7 +535,7 @@ def test_non_finite_and_negative_zero_inputs_take_the_exact_path():
     cls = rng.integers(0, 4, b).astype(np.int32)
     ax = rng.integers(0, 3, b).astype(np.int32)
     outs = [host(ops.step(dev(p), dev(cls), dev(ax), stages=7, flags=fl)["points"])
-            for fl in (0, A.HK_FLAG_FORCE_LDS_ROWS, A.HK_FLAG_FORCE_GENERIC)]
+            for fl in (0, A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC)]
     assert np.array_equal(outs[0], outs[1], equal_nan=True) and np.array_equal(outs[0], outs[2], equal_nan=True)
     clean = np.ones(b, dtype=bool)
     clean[[5, 70]] = False
