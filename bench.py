@@ -340,6 +340,8 @@ def main():
             traffic, traffic_src = measured_traffic("rollout_T20_bytes_per_launch")
         if single is not None and b == BATCH:
             single["traffic"], _ = measured_traffic("single_step_bytes_per_launch")
+        if api is not None and b == BATCH:
+            api["traffic"], _ = measured_traffic("boundary_step_bytes_per_launch")
         out = {
             "metric": "env-steps/sec at dim=3, max_pts=20, batch=65536; 1/2/4/8 GPUs",
             "value": world * b * K / elapsed,

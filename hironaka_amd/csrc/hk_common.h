@@ -17,6 +17,9 @@ constexpr int kMaxDim = 30;               // subsets travel as 32-bit masks
 constexpr unsigned kStageFeatureSort = 1u << 8;  // jax/util.py:186-197 row ordering
 
 enum Mode : int { kModeStep = 0, kModeRollout = 1, kModeGenerate = 2, kModeZeillinger = 3 };
+// template-only variant of kModeRollout: the rollout that also writes per-step observations / records
+// (kept out of the plain rollout kernel, whose loop it would cost ~40 VGPRs)
+constexpr int kModeRolloutRec = 4;
 
 // RNG stream ids (DESIGN.md "Randomness"); the oracle uses the same two numbers.
 constexpr uint32_t kStreamPolicy = 0u;

@@ -270,12 +270,14 @@ __device__ inline void fast_policy(const Params& prm, uint64_t gg, uint32_t step
   fast_policy<D>(prm.seed, prm.host_policy, prm.agent_policy, gg, step, cache, cls, axis, mask);
 }
 
-// ---- the kernel: MODE is one of kModeStep / kModeRollout / kModeGenerate -------------------------
+// ---- the kernel: MODE is one of kModeStep / kModeRollout / kModeRolloutRec / kModeGenerate -------
 template <int M, int D, int MODE>
-__global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
+__global__ __launch_bounds__(kWave, (MODE == kModeRolloutRec ? 1 : 2)) void fast_kernel(const Params prm) {
   using G = FastGeom<M, D>;
   __shared__ __align__(16) float lds[kWave * G::S];
   __shared__ float cbuf[kWave * D];  // slow path only: subset mask / row scratch per lane
+  constexpr bool kRec = MODE == kModeRolloutRec;            // rollout + per-step observations / records
+  constexpr bool kRoll = MODE == kModeRollout || kRec;
   const int lane = threadIdx.x;
   // games per wave: 64, or fewer (lanes idle) when the batch would otherwise leave the SIMDs with
   // fewer than two waves each -- see fast_games_per_block()
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
   const unsigned flags = prm.flags;
   const unsigned stages = (MODE == kModeGenerate) ? (prm.stages & ~HK_STAGE_SHIFT) : prm.stages;
   const float fill = ((flags & HK_SEM_MASK) == HK_SEM_TORCH) ? pad : -1.0f;
-  const int nsteps = (MODE == kModeRollout) ? prm.steps : 1;
+  const int nsteps = (kRoll) ? prm.steps : 1;
   PolicyCache pcache;
 
   // step mode: issue the action loads first so their latency hides under the slab copy
@@ -337,13 +339,13 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
     float* cs = cbuf + lane * D;
     np = active ? num_points<float>(mine, M, D) : 2;
     int length = (np < 2) ? 0 : -1;
-    if (MODE == kModeRollout && prm.count_ws) {
+    if (kRoll && prm.count_ws) {
       const unsigned long long b0 = __ballot(active && np < 2);
       if (lane == 0) prm.count_ws[blockIdx.x] = (uint32_t)__popcll(b0);
     }
     for (int t = 0; t < nsteps; ++t) {
       int axis = -1, cls = 0;
-      if (MODE == kModeRollout) {
+      if (kRoll) {
         if (prm.obs_out) {
           __syncthreads();
           fast_store_slab<M, D>(lds, (float*)prm.obs_out + (int64_t)t * prm.batch * G::N, (int64_t)G::N,
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
       np = active ? num_points<float>(mine, prm.m, prm.d) : 2;
       const bool done = np < 2;
       if (done && length < 0) length = t + 1;
-      if (MODE == kModeRollout) {
+      if (kRoll) {
         if (active) {
           const int64_t at = (int64_t)t * prm.batch + g;
           if (prm.r_host_class_out) prm.r_host_class_out[at] = cls;
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
         if (prm.num_points_out) prm.num_points_out[g] = np;
       }
     }
-    if (MODE == kModeRollout && active && prm.game_length_out) prm.game_length_out[g] = length;
+    if (kRoll && active && prm.game_length_out) prm.game_length_out[g] = length;
     __syncthreads();
     fast_store_slab<M, D>(lds, (float*)prm.out, prm.out_stride, g0, ngames, lane);
     return;
@@ -389,10 +391,12 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
 
   // ---- 3. gather the live rows ------------------------------------------------------------------------
   float q[G::C * D];
+#pragma unroll
+  for (int e = 0; e < G::C * D; ++e) q[e] = INFINITY;  // rows past nmax are holes in the straight-line bodies
   gather_rows<M, G::C, D>(q, mine, gmask, nmax);
   if (!active) np = 2;  // never "done", never counted
   int length = (np < 2) ? 0 : -1;
-  if (MODE == kModeRollout && prm.count_ws) {
+  if (kRoll && prm.count_ws) {
     const unsigned long long b0 = __ballot(active && np < 2);
     if (lane == 0) prm.count_ws[blockIdx.x] = (uint32_t)__popcll(b0);
   }
@@ -401,10 +405,10 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
   // Wave-uniform facts about the optional outputs are computed ONCE: tested per step through the
   // kernel-argument struct, SGPR pressure makes the compiler re-issue the 64-byte s_load of the pointer
   // block (and a full s_waitcnt) several times per step.
-  const bool want_obs = (MODE == kModeRollout) && prm.obs_out != nullptr;
-  const bool want_records = (MODE == kModeRollout) && (prm.r_host_class_out || prm.r_axis_out ||
+  const bool want_obs = kRec && prm.obs_out != nullptr;
+  const bool want_records = kRec && (prm.r_host_class_out || prm.r_axis_out ||
                                                        prm.r_done_out || prm.r_reward_out);
-  uint32_t* count_slot = (MODE == kModeRollout && prm.count_ws) ? prm.count_ws + blockIdx.x : nullptr;
+  uint32_t* count_slot = (kRoll && prm.count_ws) ? prm.count_ws + blockIdx.x : nullptr;
   uint32_t count_stride = gridDim.x;
   uint32_t step0 = prm.step_offset;
   uint64_t seed = prm.seed;
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
                "+s"(agent_policy));
   for (int t = 0; t < nsteps; ++t) {
     int axis = -1, cls = 0;
-    if (MODE == kModeRollout) {
+    if (kRoll) {
       if (want_obs) {  // state before the step: rebuild the image, store it coalesced
         __syncthreads();
         fill_image<M, D>(mine, pad);
@@ -433,15 +437,11 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
     }
     const bool prev_done = np < 2;
 
-    if (stages & HK_STAGE_SHIFT) c_shift<G::C, D>(q, nmax, c, axis, np, flags);
-    if (stages & HK_STAGE_REPOSITION) c_reposition<G::C, D>(q, nmax, flags);
-    if (stages & HK_STAGE_NEWTON) c_newton<G::C, D>(q, nmax);
-    if (stages & HK_STAGE_RESCALE) c_rescale<G::C, D>(q, nmax, flags);
-
-    np = active ? count_live<G::C, D>(q, nmax) : 2;
+    np = run_stages<G::C, D>(q, nmax, c, axis, np, flags, stages);  // branch-free body for >= nmax rows
+    if (!active) np = 2;
     const bool done = np < 2;
     if (done && length < 0) length = t + 1;
-    if (MODE == kModeRollout) {
+    if (kRoll) {
       if (want_records && active) {
         const int64_t at = (int64_t)t * prm.batch + g;
         if (prm.r_host_class_out) prm.r_host_class_out[at] = cls;
@@ -457,8 +457,9 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
       // (one ballot per step; the cross-lane maximum only when some game still fills all nmax rows)
       if (t + 1 < nsteps && !__any(active && np >= nmax)) {
         gmask = scatter_rows<M, G::C, D>(q, mine, gmask, nmax);
+        const int nprev = nmax;
         nmax = wave_max(active ? np : 0, nmax - 1);
-        gather_rows<M, G::C, D>(q, mine, gmask, nmax);
+        gather_rows<M, G::C, D>(q, mine, gmask, nprev);  // rows [nmax, nprev) become holes again
       }
     } else if (MODE == kModeStep && active) {
       if (prm.done_out) prm.done_out[g] = done;
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
       if (prm.num_points_out) prm.num_points_out[g] = np;
     }
   }
-  if (MODE == kModeRollout && active && prm.game_length_out) prm.game_length_out[g] = length;
+  if (kRoll && active && prm.game_length_out) prm.game_length_out[g] = length;
 
   // ---- 5. publish: pad everywhere, live rows back in their slots ---------------------------------
   __syncthreads();
@@ -480,7 +481,9 @@ __global__ __launch_bounds__(kWave) void fast_kernel(const Params prm) {
 // ---- the specialisation table ------------------------------------------------------------------
 // (max_points, dim): BASELINE configs (10,3) (20,3) (50,4) plus the small shapes the reference's
 // tests and YAMLs use.
+#ifndef HK_FAST_SPECS  // (a build experiment may narrow the table)
 #define HK_FAST_SPECS(X) X(4, 3) X(5, 3) X(10, 3) X(16, 3) X(20, 3) X(8, 4) X(20, 4)
+#endif
 
 inline int has_fast_path(int m, int d, int dtype) {
   if (dtype != HK_F32) return 0;
@@ -527,6 +530,9 @@ int launch_fast_t(Params prm, hipStream_t stream) {
   launch_prepare();
   if (prm.mode == kModeStep)
     hipLaunchKernelGGL((fast_kernel<M, D, kModeStep>), dim3(grid), dim3(kWave), 0, stream, prm);
+  else if (prm.mode == kModeRollout && (prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out ||
+                                        prm.r_reward_out))
+    hipLaunchKernelGGL((fast_kernel<M, D, kModeRolloutRec>), dim3(grid), dim3(kWave), 0, stream, prm);
   else if (prm.mode == kModeRollout)
     hipLaunchKernelGGL((fast_kernel<M, D, kModeRollout>), dim3(grid), dim3(kWave), 0, stream, prm);
   else

@@ -217,4 +217,136 @@ __device__ __forceinline__ void c_rescale(float (&q)[C * D], int nmax, unsigned 
   });
 }
 
+// ---- straight-line bodies ------------------------------------------------------------------------------
+// A lone wave per SIMD issues ONE instruction (of any kind) per four cycles, so the scalar compare +
+// branch that ends each row loop early costs as much as the vector work it guards, and every taken
+// branch adds a fetch bubble.  The whole step therefore also exists as branch-free code for NB rows,
+// NB = 1..8, 10, 12, ... C, and the wave runs the smallest body that covers nmax (rows in [nmax, NB) are
+// +inf holes: they cost a few idle vector instructions and change nothing).
+template <int C, int D, int NB>
+__device__ __forceinline__ void b_shift(float (&q)[C * D], const float (&c)[D], int axis, int np, unsigned flags) {
+  bool apply = true;
+  if (flags & HK_FLAG_AXIS_NOOP_IF_INVALID) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const float onehot = (k == axis) ? 1.0f : 0.0f;
+      if (!(onehot - c[k] <= 0.0f)) apply = false;
+    }
+  }
+  if ((flags & HK_FLAG_IGNORE_ENDED) && np < 2) apply = false;
+  bool isax[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) isax[k] = apply && (k == axis);
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < D; ++k) s = s + q[r * D + k] * c[k];  // order 0..D-1, no contraction
+    const bool live = q[r * D] < INFINITY;                   // holes would give inf*0 = NaN
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[r * D + k] = (live && isax[k]) ? s : q[r * D + k];
+  }
+}
+
+template <int C, int D, int NB>
+__device__ __forceinline__ void b_reposition(float (&q)[C * D], unsigned flags) {
+  const bool jax_sem = (flags & HK_SEM_MASK) == HK_SEM_JAX;
+  float mn[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) mn[k] = INFINITY;
+#pragma unroll
+  for (int r = 0; r < NB; ++r)
+#pragma unroll
+    for (int k = 0; k < D; ++k) mn[k] = hk_fmin(mn[k], q[r * D + k]);
+  float sub[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k)  // JAX leaves a column whose minimum is <= 0 untouched: subtract 0
+    sub[k] = (mn[k] < INFINITY && (!jax_sem || mn[k] > 0.0f)) ? mn[k] : 0.0f;
+#pragma unroll
+  for (int r = 0; r < NB; ++r)
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[r * D + k] = q[r * D + k] - sub[k];  // inf - sub = inf: holes stay
+}
+
+template <int C, int D, int NB>
+__device__ __forceinline__ void b_newton(float (&q)[C * D]) {
+  float acc[NB];
+#pragma unroll
+  for (int r = 0; r < NB; ++r) acc[r] = INFINITY;
+#pragma unroll
+  for (int i = 0; i + 1 < NB; ++i) {
+#pragma unroll
+    for (int j = i + 1; j < NB; ++j) {
+      float t, u;
+      diff_extrema<D>(&q[i * D], &q[j * D], t, u);
+      acc[j] = hk_fmin(acc[j], t);
+      acc[i] = hk_fmin(acc[i], (t > 0.0f) ? -u : 1.0f);
+    }
+    // the pairs are all independent; left alone the scheduler interleaves hundreds of them and the
+    // differences in flight overflow the register file.  One row of pairs at a time is plenty of ILP.
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    const bool removed = acc[r] <= 0.0f;
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[r * D + k] = removed ? INFINITY : q[r * D + k];
+  }
+}
+
+template <int C, int D, int NB>
+__device__ __forceinline__ void b_rescale(float (&q)[C * D], unsigned flags) {
+  const bool jax_sem = (flags & HK_SEM_MASK) == HK_SEM_JAX;
+  float mx = -1.0f;
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    const bool live = q[r * D] < INFINITY;
+#pragma unroll
+    for (int k = 0; k < D; ++k) mx = hk_fmax(mx, live ? q[r * D + k] : -1.0f);
+  }
+  const bool skip = jax_sem ? (mx <= 1e-8f) : (mx < 0.0f);
+  const float div = (skip || mx == 0.0f) ? 1.0f : mx;
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    const bool live = q[r * D] < INFINITY;
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[r * D + k] = live ? q[r * D + k] / div : INFINITY;
+  }
+}
+
+// one transition on rows [0, NB); returns the number of live rows
+template <int C, int D, int NB>
+__device__ __forceinline__ int b_stages(float (&q)[C * D], const float (&c)[D], int axis, int np, unsigned flags,
+                                        unsigned stages) {
+  if (stages & HK_STAGE_SHIFT) b_shift<C, D, NB>(q, c, axis, np, flags);
+  if (stages & HK_STAGE_REPOSITION) b_reposition<C, D, NB>(q, flags);
+  if (stages & HK_STAGE_NEWTON) b_newton<C, D, NB>(q);
+  if (stages & HK_STAGE_RESCALE) b_rescale<C, D, NB>(q, flags);
+  int n = 0;
+#pragma unroll
+  for (int r = 0; r < NB; ++r) n += (q[r * D] < INFINITY) ? 1 : 0;
+  return n;
+}
+
+// the smallest body that covers nmax
+template <int C, int D, int NB>
+struct StagesFor {
+  static constexpr int kNext = (NB < 8) ? NB + 1 : NB + 2;
+  static __device__ __forceinline__ int run(float (&q)[C * D], int nmax, const float (&c)[D], int axis, int np,
+                                            unsigned flags, unsigned stages) {
+    if constexpr (NB >= C) {
+      return b_stages<C, D, C>(q, c, axis, np, flags, stages);
+    } else {
+      if (nmax <= NB) return b_stages<C, D, NB>(q, c, axis, np, flags, stages);
+      return StagesFor<C, D, kNext>::run(q, nmax, c, axis, np, flags, stages);
+    }
+  }
+};
+
+template <int C, int D>
+__device__ __forceinline__ int run_stages(float (&q)[C * D], int nmax, const float (&c)[D], int axis, int np,
+                                          unsigned flags, unsigned stages) {
+  return StagesFor<C, D, 1>::run(q, nmax, c, axis, np, flags, stages);
+}
+
 }  // namespace hk
