@@ -271,8 +271,12 @@ __device__ inline void fast_policy(const Params& prm, uint64_t gg, uint32_t step
 }
 
 // ---- the kernel: MODE is one of kModeStep / kModeRollout / kModeRolloutRec / kModeGenerate -------
-template <int M, int D, int MODE>
-__global__ __launch_bounds__(kWave, (MODE == kModeRolloutRec ? 1 : 2)) void fast_kernel(const Params prm) {
+// HOT: the configuration of the JAX trainer's rollouts (shift + reposition + Newton polytope, JAX
+// semantics without behaviour flags, uniformly random host and agent) as compile-time constants.  A lone
+// wave per SIMD pays a fetch bubble for every taken branch, and the per-step tests of stages / flags /
+// policies are ~15 % of a fused rollout (measured: 43.5 -> 38.1 us per 20-step episode of 65 536 games).
+template <int M, int D, int MODE, bool HOT = false>
+__global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1 : 2)) void fast_kernel(const Params prm) {
   using G = FastGeom<M, D>;
   __shared__ __align__(16) float lds[kWave * G::S];
   __shared__ float cbuf[kWave * D];  // slow path only: subset mask / row scratch per lane
@@ -290,8 +294,9 @@ __global__ __launch_bounds__(kWave, (MODE == kModeRolloutRec ? 1 : 2)) void fast
   const uint64_t gg = prm.game_offset + (uint64_t)g;
   float* mine = lds + lane * G::S;
   const float pad = (float)prm.pad;
-  const unsigned flags = prm.flags;
-  const unsigned stages = (MODE == kModeGenerate) ? (prm.stages & ~HK_STAGE_SHIFT) : prm.stages;
+  const unsigned flags = HOT ? (unsigned)HK_SEM_JAX : prm.flags;
+  const unsigned stages = HOT ? (unsigned)(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON)
+                              : (MODE == kModeGenerate) ? (prm.stages & ~HK_STAGE_SHIFT) : prm.stages;
   const float fill = ((flags & HK_SEM_MASK) == HK_SEM_TORCH) ? pad : -1.0f;
   const int nsteps = (kRoll) ? prm.steps : 1;
   PolicyCache pcache;
@@ -412,11 +417,15 @@ __global__ __launch_bounds__(kWave, (MODE == kModeRolloutRec ? 1 : 2)) void fast
   uint32_t count_stride = gridDim.x;
   uint32_t step0 = prm.step_offset;
   uint64_t seed = prm.seed;
-  int host_policy = prm.host_policy, agent_policy = prm.agent_policy;
+  int host_policy = HOT ? (int)HK_HOST_RANDOM : prm.host_policy;
+  int agent_policy = HOT ? (int)HK_AGENT_RANDOM : prm.agent_policy;
   // opaque to the optimiser: the values now "come from" the asm, so they stay in SGPRs (or a VGPR lane)
   // instead of being re-loaded from the kernel-argument / dispatch memory inside the loop
-  asm volatile("" : "+s"(count_slot), "+s"(count_stride), "+s"(step0), "+s"(seed), "+s"(host_policy),
-               "+s"(agent_policy));
+  if (HOT)
+    asm volatile("" : "+s"(count_slot), "+s"(count_stride), "+s"(step0), "+s"(seed));
+  else
+    asm volatile("" : "+s"(count_slot), "+s"(count_stride), "+s"(step0), "+s"(seed), "+s"(host_policy),
+                 "+s"(agent_policy));
   for (int t = 0; t < nsteps; ++t) {
     int axis = -1, cls = 0;
     if (kRoll) {
@@ -523,6 +532,11 @@ inline int fast_games_per_block(const Params& prm) {
   return kWave;
 }
 
+inline bool fast_hot_config(const Params& prm) {
+  return prm.stages == (HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON) && prm.flags == HK_SEM_JAX &&
+         prm.host_policy == HK_HOST_RANDOM && prm.agent_policy == HK_AGENT_RANDOM;
+}
+
 template <int M, int D>
 int launch_fast_t(Params prm, hipStream_t stream) {
   prm.games_per_block = fast_games_per_block(prm);
@@ -533,6 +547,8 @@ int launch_fast_t(Params prm, hipStream_t stream) {
   else if (prm.mode == kModeRollout && (prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out ||
                                         prm.r_reward_out))
     hipLaunchKernelGGL((fast_kernel<M, D, kModeRolloutRec>), dim3(grid), dim3(kWave), 0, stream, prm);
+  else if (prm.mode == kModeRollout && fast_hot_config(prm))
+    hipLaunchKernelGGL((fast_kernel<M, D, kModeRollout, true>), dim3(grid), dim3(kWave), 0, stream, prm);
   else if (prm.mode == kModeRollout)
     hipLaunchKernelGGL((fast_kernel<M, D, kModeRollout>), dim3(grid), dim3(kWave), 0, stream, prm);
   else
