@@ -158,9 +158,19 @@ def main():
     kw = dict(game_offset=game_offset, stages=stages, host_policy=A.HK_HOST_RANDOM,
               agent_policy=A.HK_AGENT_RANDOM)
 
+    count_ws = ops.rollout_workspace(b, EPISODE, (m, d))
+
     def episode(n_steps):
         # the episode restarts from the resident fresh states: the kernel reads `fresh`, writes `state`
         ops.rollout(state, n_steps, SEED, done_count=done_count[: n_steps + 1], initial=fresh, **kw)
+
+    def episodes_deferred(n_episodes):
+        # full episodes back to back; the per-workgroup finished-game counts accumulate in `count_ws` and are
+        # summed into done_count ONCE (the reference sums its per-loop histograms the same way,
+        # jax_trainer.py:513,533-534)
+        for _ in range(n_episodes):
+            ops.rollout(state, EPISODE, SEED, initial=fresh, defer_counts=True, workspace=count_ws, **kw)
+        ops.reduce_counts(count_ws, done_count, b, EPISODE, (m, d))
 
     def episode_stepwise(n_steps):
         for t in range(n_steps):
@@ -173,7 +183,9 @@ def main():
         episode_stepwise(1)
         torch.cuda.synchronize()
         g_episode = capture(lambda: episode(EPISODE))
-        g_block = capture(lambda: [episode(EPISODE) for _ in range(BLOCK)])  # BLOCK episodes per replay
+        episodes_deferred(1)
+        torch.cuda.synchronize()
+        g_block = capture(lambda: episodes_deferred(BLOCK))  # BLOCK episodes + one counter reduce per replay
         g_rem = capture(lambda: episode(rem)) if rem else None
         g_stepwise = None if args.no_single_step else capture(lambda: episode_stepwise(EPISODE))
     torch.cuda.synchronize()
@@ -361,7 +373,8 @@ def main():
                             f"{EPISODE} steps from generate_pts states (max_value={MAX_VALUE}); fused rollout: "
                             f"{EPISODE} env steps per launch",
                 "parallelism": f"{world} x independent game shards, all-gather of final states",
-                "launch": f"hipGraph replay ({BLOCK} episodes per graph): rollout kernel + counter reduce per episode",
+                "launch": f"hipGraph replay ({BLOCK} episodes per graph): one rollout kernel per episode, one "
+                          f"counter reduce per graph",
             },
             "roofline": {
                 "bound": "hbm",

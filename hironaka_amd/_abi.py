@@ -38,6 +38,7 @@ HK_FLAG_IGNORE_ENDED = 8
 HK_FLAG_COMPACT_SORTED = 16
 HK_FLAG_FORCE_GENERIC = 32
 HK_FLAG_FORCE_TEAM = 64
+HK_FLAG_DEFER_COUNTS = 128
 
 # fused policies
 HK_HOST_RANDOM, HK_HOST_ALL_COORD, HK_HOST_ZEILLINGER = 0, 1, 2
@@ -121,6 +122,7 @@ PROTOTYPES = {
     "hk_generate_points": (C.c_int, [_vp, _i, _i, _i, _i, _i, _u64, _u64, _u32, _d, _u32, _vp]),
     "hk_rollout": (C.c_int, [C.POINTER(hk_rollout_desc), _vp]),
     "hk_rollout_workspace_bytes": (C.c_uint64, [C.POINTER(hk_rollout_desc)]),
+    "hk_rollout_reduce_counts": (C.c_int, [C.POINTER(hk_rollout_desc), C.c_void_p]),
     "hk_zeillinger": (C.c_int, [_vp, _i64, _vp, _i, _i, _i, _i, _u32, _vp]),
     "hk_get_features": (C.c_int, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _d, _vp]),
     "hk_decode_host_class": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),

@@ -319,15 +319,24 @@ static int params_from_rollout(const hk_rollout_desc* r, Params& prm) {
   prm.m = r->max_points;
   prm.d = r->dim;
   prm.stages = r->stages;
-  prm.flags = r->flags;
+  prm.flags = r->flags & ~HK_FLAG_DEFER_COUNTS;  // host-side only: the kernels always add to the workspace
   prm.mode = kModeRollout;
   return HK_OK;
 }
 
 uint64_t hk_rollout_workspace_bytes(const hk_rollout_desc* r) {
   Params prm{};
-  if (params_from_rollout(r, prm) != HK_OK || prm.batch == 0 || !r->done_count) return 0;
+  if (params_from_rollout(r, prm) != HK_OK || prm.batch == 0) return 0;
   return (uint64_t)planned_grid(prm, r->dtype) * (uint64_t)(r->steps + 1) * sizeof(uint32_t);
+}
+
+// workspace checks shared by hk_rollout and hk_rollout_reduce_counts
+static int counts_workspace(const hk_rollout_desc* r, int64_t grid, uint32_t** ws) {
+  if (!r->workspace) return HK_ERR_NULL;
+  if (!aligned(r->workspace, 4)) return HK_ERR_ALIGN;
+  if (r->workspace_bytes < (uint64_t)grid * (uint64_t)(r->steps + 1) * sizeof(uint32_t)) return HK_ERR_SHAPE;
+  *ws = (uint32_t*)r->workspace;
+  return HK_OK;
 }
 
 int hk_rollout(const hk_rollout_desc* r, void* stream) {
@@ -337,16 +346,33 @@ int hk_rollout(const hk_rollout_desc* r, void* stream) {
   if (prm.batch == 0) return HK_OK;
   const int64_t grid = planned_grid(prm, r->dtype);
   if (grid == 0) return HK_ERR_UNSUPPORTED;
-  if (r->done_count) {
-    if (!r->workspace) return HK_ERR_NULL;
-    if (!aligned(r->workspace, 4)) return HK_ERR_ALIGN;
-    if (r->workspace_bytes < (uint64_t)grid * (uint64_t)(r->steps + 1) * sizeof(uint32_t)) return HK_ERR_SHAPE;
-    prm.count_ws = (uint32_t*)r->workspace;
+  const bool defer = (r->flags & HK_FLAG_DEFER_COUNTS) != 0;
+  if (r->done_count || defer) {
+    const int ws = counts_workspace(r, grid, &prm.count_ws);
+    if (ws != HK_OK) return ws;
   }
   const int ls = launch(prm, r->dtype, (hipStream_t)stream);
-  if (ls != HK_OK || !r->done_count) return ls;
+  if (ls != HK_OK || !r->done_count || defer) return ls;
   return launch_count_reduce(prm.count_ws, (int)grid, r->steps, (unsigned long long*)r->done_count,
                              (hipStream_t)stream);
+}
+
+int hk_rollout_reduce_counts(const hk_rollout_desc* desc, void* stream) {
+  if (!desc) return HK_ERR_NULL;
+  hk_rollout_desc copy = *desc;  // only the launch geometry matters here: `points` may be NULL
+  if (!copy.points) copy.points = copy.workspace;
+  const hk_rollout_desc* r = &copy;
+  Params prm{};
+  const int st = params_from_rollout(r, prm);
+  if (st != HK_OK) return st;
+  if (!r->done_count) return HK_ERR_NULL;
+  if (prm.batch == 0) return HK_OK;
+  const int64_t grid = planned_grid(prm, r->dtype);
+  if (grid == 0) return HK_ERR_UNSUPPORTED;
+  uint32_t* ws = nullptr;
+  const int wst = counts_workspace(r, grid, &ws);
+  if (wst != HK_OK) return wst;
+  return launch_count_reduce(ws, (int)grid, r->steps, (unsigned long long*)r->done_count, (hipStream_t)stream);
 }
 
 int hk_zeillinger(const void* points, int64_t stride, int32_t* class_out, int batch,

@@ -151,6 +151,14 @@ __device__ inline double load_scalar(const void* base, int dtype, size_t idx) {
   return 0.0;
 }
 
+// A workgroup's finished-game count of one step goes to its own slot of the caller's workspace, ADDED
+// (an atomic nobody waits for; the slot is private, so there is no contention): the slots start at zero,
+// accumulate over as many launches as the caller defers the reduction for (HK_FLAG_DEFER_COUNTS), and are
+// zeroed again by the reduce kernel that sums them into done_count.
+__device__ __forceinline__ void count_add(uint32_t* slot, uint32_t v) {
+  __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // The same fetch split in two, branch-free in the part that touches memory: `fetch_raw` requests the
 // aligned dword(s) holding element idx (the upper request repeats the lower one for elements narrower
 // than 8 bytes, so every address is inside the caller's array's own words), and nothing looks at the

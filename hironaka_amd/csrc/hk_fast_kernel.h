@@ -346,7 +346,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
     int length = (np < 2) ? 0 : -1;
     if (kRoll && prm.count_ws) {
       const unsigned long long b0 = __ballot(active && np < 2);
-      if (lane == 0) prm.count_ws[blockIdx.x] = (uint32_t)__popcll(b0);
+      if (lane == 0) count_add(prm.count_ws + blockIdx.x, (uint32_t)__popcll(b0));
     }
     for (int t = 0; t < nsteps; ++t) {
       int axis = -1, cls = 0;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
         }
         if (prm.count_ws) {
           const unsigned long long bd = __ballot(active && done);
-          if (lane == 0) prm.count_ws[(size_t)(t + 1) * gridDim.x + blockIdx.x] = (uint32_t)__popcll(bd);
+          if (lane == 0) count_add(prm.count_ws + (size_t)(t + 1) * gridDim.x + blockIdx.x, (uint32_t)__popcll(bd));
         }
       } else if (MODE == kModeStep && active) {
         if (prm.done_out) prm.done_out[g] = done;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   int length = (np < 2) ? 0 : -1;
   if (kRoll && prm.count_ws) {
     const unsigned long long b0 = __ballot(active && np < 2);
-    if (lane == 0) prm.count_ws[blockIdx.x] = (uint32_t)__popcll(b0);
+    if (lane == 0) count_add(prm.count_ws + blockIdx.x, (uint32_t)__popcll(b0));
   }
 
   // ---- 4. the transitions --------------------------------------------------------------------------
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
       }
       if (count_slot) {
         const unsigned long long bd = __ballot(active && done);
-        if (lane == 0) count_slot[(size_t)(t + 1) * count_stride] = (uint32_t)__popcll(bd);
+        if (lane == 0) count_add(count_slot + (size_t)(t + 1) * count_stride, (uint32_t)__popcll(bd));
       }
       // re-gather when the widest game of the wave got narrower (removed rows are holes until then)
       // (one ballot per step; the cross-lane maximum only when some game still fills all nmax rows)
@@ -578,14 +578,17 @@ inline int launch_fast(const Params& prm, hipStream_t stream) {
 }
 
 // ---- finished-game counters: per-workgroup partials -> done_count ---------------------------------
-// block t sums count_ws[t][0..nblocks) and adds it to done_count[t]: steps+1 atomics in total
-// instead of (steps+1) * nblocks on one cache line.
-__global__ __launch_bounds__(256) void count_reduce_kernel(const uint32_t* ws, int nblocks,
+// block t sums count_ws[t][0..nblocks), adds it to done_count[t] (steps+1 atomics in total instead of
+// (steps+1) * nblocks on one cache line) and leaves the partials zeroed for the next launches.
+__global__ __launch_bounds__(256) void count_reduce_kernel(uint32_t* ws, int nblocks,
                                                            unsigned long long* done_count) {
   __shared__ unsigned long long part[256 / kWave];
-  const uint32_t* row = ws + (size_t)blockIdx.x * nblocks;
+  uint32_t* row = ws + (size_t)blockIdx.x * nblocks;
   unsigned long long s = 0;
-  for (int i = threadIdx.x; i < nblocks; i += 256) s += row[i];
+  for (int i = threadIdx.x; i < nblocks; i += 256) {
+    s += row[i];
+    row[i] = 0;
+  }
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) s += __shfl_down(s, off, kWave);
   if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = s;
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(256) void count_reduce_kernel(const uint32_t* ws, i
   }
 }
 
-inline int launch_count_reduce(const uint32_t* ws, int nblocks, int steps, unsigned long long* done_count,
+inline int launch_count_reduce(uint32_t* ws, int nblocks, int steps, unsigned long long* done_count,
                                hipStream_t stream) {
   launch_prepare();
   hipLaunchKernelGGL(count_reduce_kernel, dim3(steps + 1), dim3(256), 0, stream, ws, nblocks, done_count);

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kWave) void generic_kernel(const Params prm) {
   int length = (np < 2) ? 0 : -1;
   if (prm.count_ws) {
     const unsigned long long b0 = __ballot(active && np < 2);
-    if (lane == 0) prm.count_ws[blockIdx.x] = (uint32_t)__popcll(b0);
+    if (lane == 0) count_add(prm.count_ws + blockIdx.x, (uint32_t)__popcll(b0));
   }
   for (int t = 0; t < prm.steps; ++t) {
     if (prm.obs_out) {  // state before the step, coalesced
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kWave) void generic_kernel(const Params prm) {
     }
     if (prm.count_ws) {
       const unsigned long long bd = __ballot(active && done);
-      if (lane == 0) prm.count_ws[(size_t)(t + 1) * gridDim.x + blockIdx.x] = (uint32_t)__popcll(bd);
+      if (lane == 0) count_add(prm.count_ws + (size_t)(t + 1) * gridDim.x + blockIdx.x, (uint32_t)__popcll(bd));
     }
     __syncthreads();
   }

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
     int length = (np < 2) ? 0 : -1;
     if (MODE == kModeRollout && prm.count_ws) {
       const unsigned long long b0 = __ballot(leader && np < 2);
-      if (lane == 0) prm.count_ws[blockIdx.x] = (uint32_t)__popcll(b0);
+      if (lane == 0) count_add(prm.count_ws + blockIdx.x, (uint32_t)__popcll(b0));
     }
     for (int t = 0; t < nsteps; ++t) {
       int axis = -1, cls = 0;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
         }
         if (prm.count_ws) {
           const unsigned long long bd = __ballot(leader && done);
-          if (lane == 0) prm.count_ws[(size_t)(t + 1) * gridDim.x + blockIdx.x] = (uint32_t)__popcll(bd);
+          if (lane == 0) count_add(prm.count_ws + (size_t)(t + 1) * gridDim.x + blockIdx.x, (uint32_t)__popcll(bd));
         }
       } else if (MODE == kModeStep && leader) {
         if (prm.done_out) prm.done_out[g] = done;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
   int length = (np < 2) ? 0 : -1;
   if (MODE == kModeRollout && prm.count_ws) {
     const unsigned long long b0 = __ballot(leader && np < 2);
-    if (lane == 0) prm.count_ws[blockIdx.x] = (uint32_t)__popcll(b0);
+    if (lane == 0) count_add(prm.count_ws + blockIdx.x, (uint32_t)__popcll(b0));
   }
 
   // ---- 4. the transitions --------------------------------------------------------------------------
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
       }
       if (prm.count_ws) {
         const unsigned long long bd = __ballot(leader && done);
-        if (lane == 0) prm.count_ws[(size_t)(t + 1) * gridDim.x + blockIdx.x] = (uint32_t)__popcll(bd);
+        if (lane == 0) count_add(prm.count_ws + (size_t)(t + 1) * gridDim.x + blockIdx.x, (uint32_t)__popcll(bd));
       }
       // squeeze when the widest game of the wave got narrower: live rows to their new ranks in the
       // region, then every lane takes back rows 4s+tl

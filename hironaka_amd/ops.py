@@ -295,14 +295,49 @@ _WORKSPACES: Dict[Tuple[torch.device, int], torch.Tensor] = {}
 
 
 def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
-    """Per-(device, stream) scratch for hk_rollout's per-workgroup counters, grown on demand
-    (the C ABI never allocates; contents need no initialisation)."""
+    """Per-(device, stream) memory for hk_rollout's per-workgroup counters, grown on demand (the C ABI
+    never allocates).  Zero when created; every reduction leaves it zero again."""
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
+        ws = torch.zeros(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
         _WORKSPACES[key] = ws
     return ws
+
+
+def _geometry_desc(batch: int, steps: int, spec: Tuple[int, int], dtype, flags: int) -> "A.hk_rollout_desc":
+    r = A.hk_rollout_desc()
+    r.batch, r.max_points, r.dim, r.dtype, r.steps = batch, spec[0], spec[1], _TORCH2HK[dtype], steps
+    r.host_policy, r.agent_policy, r.flags = A.HK_HOST_RANDOM, A.HK_AGENT_RANDOM, flags
+    r.stages = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON
+    return r
+
+
+def rollout_workspace(batch: int, steps: int, spec: Tuple[int, int], dtype=torch.float32, device=None,
+                      flags: int = 0) -> torch.Tensor:
+    """A zeroed counter workspace of the caller's own, for rollouts with `defer_counts=True`."""
+    dev = torch.device("cuda") if device is None else torch.device(device)
+    r = _geometry_desc(batch, steps, spec, dtype, flags)
+    probe = torch.empty(8, dtype=torch.uint8, device=dev)
+    r.points = probe.data_ptr()
+    need = lib().hk_rollout_workspace_bytes(C.byref(r))
+    return torch.zeros(max(int(need), 8), dtype=torch.uint8, device=dev)
+
+
+def reduce_counts(workspace: torch.Tensor, done_count: torch.Tensor, batch: int, steps: int,
+                  spec: Tuple[int, int], dtype=torch.float32, flags: int = 0) -> torch.Tensor:
+    """done_count += the partial counts that rollouts with `defer_counts=True` left in `workspace`
+    (hk_rollout_reduce_counts); the workspace is zero afterwards."""
+    _require_device(workspace, "workspace")
+    _require_device(done_count, "done_count")
+    if done_count.dtype != torch.int64 or done_count.numel() != steps + 1:
+        raise ValueError("done_count must be an int64 device tensor of steps+1 elements")
+    r = _geometry_desc(batch, steps, spec, dtype, flags)
+    r.done_count = done_count.data_ptr()
+    r.workspace, r.workspace_bytes = workspace.data_ptr(), workspace.numel()
+    with torch.cuda.device(workspace.device):
+        check(lib().hk_rollout_reduce_counts(C.byref(r), _stream(workspace)), "hk_rollout_reduce_counts")
+    return done_count
 
 
 def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0, step_offset: int = 0,
@@ -310,12 +345,16 @@ def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0
             stages: int = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON, flags: int = 0,
             padding_value: float = -1.0, reward_sign: float = 1.0, record: Sequence[str] = (),
             done_count: Optional[torch.Tensor] = None,
-            initial: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+            initial: Optional[torch.Tensor] = None, defer_counts: bool = False,
+            workspace: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """T fused steps with in-kernel policies (hk_rollout); `points` is updated IN PLACE.
     record: any of "obs", "host_class", "axis", "done", "reward", "game_length".
     done_count: optional uint64-as-int64 [steps+1] accumulator (zeroed by the caller).
     initial: optional tensor like `points` holding the starting state; it is left untouched and
-        `points` only receives the final state (an episode restart without a device copy)."""
+        `points` only receives the final state (an episode restart without a device copy).
+    defer_counts: leave the finished-game counts as partial sums in `workspace` (from `rollout_workspace`;
+        they accumulate over launches) and skip the reduce kernel; `reduce_counts` adds them to a
+        done_count later -- one reduction for many rollouts."""
     _require_device(points, "points")
     if points.dtype not in (torch.float32, torch.float64) or not points.is_contiguous() or points.dim() != 3:
         raise ValueError("rollout updates a contiguous [B, m, d] float32/float64 tensor in place")
@@ -328,11 +367,17 @@ def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0
             raise ValueError("initial must match points in shape, dtype, device and be contiguous")
     r = A.hk_rollout_desc()
     res: Dict[str, torch.Tensor] = {}
-    if done_count is None:
+    if defer_counts:
+        if workspace is None:
+            raise ValueError("defer_counts=True needs the caller's own workspace (ops.rollout_workspace)")
+        _require_device(workspace, "workspace")
+        flags |= A.HK_FLAG_DEFER_COUNTS
+    elif done_count is None:
         done_count = torch.zeros(steps + 1, dtype=torch.int64, device=dev)
     elif done_count.dtype != torch.int64 or done_count.numel() != steps + 1 or not done_count.is_cuda:
         raise ValueError("done_count must be an int64 device tensor of steps+1 elements")
-    res["done_count"] = done_count
+    if done_count is not None:
+        res["done_count"] = done_count
     for key in record:
         if key == "obs":
             res[key] = torch.empty((steps, b, m, d), dtype=points.dtype, device=dev)
@@ -347,7 +392,8 @@ def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0
         else:
             raise ValueError(f"unknown record {key}")
     ptr = lambda k: res[k].data_ptr() if k in res else None
-    r.points, r.done_count = points.data_ptr(), done_count.data_ptr()
+    r.points = points.data_ptr()
+    r.done_count = done_count.data_ptr() if (done_count is not None and not defer_counts) else None
     r.points_in = initial.data_ptr() if initial is not None else None
     r.obs_out, r.host_class_out, r.axis_out = ptr("obs"), ptr("host_class"), ptr("axis")
     r.done_out, r.reward_out, r.game_length_out = ptr("done"), ptr("reward"), ptr("game_length")
@@ -355,8 +401,7 @@ def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0
     r.padding_value, r.reward_sign = float(padding_value), float(reward_sign)
     r.batch, r.max_points, r.dim, r.dtype, r.steps = b, m, d, _TORCH2HK[points.dtype], steps
     r.host_policy, r.agent_policy, r.stages, r.flags = host_policy, agent_policy, stages, flags
-    need = lib().hk_rollout_workspace_bytes(C.byref(r))
-    ws = _workspace(dev, need)
+    ws = workspace if defer_counts else _workspace(dev, lib().hk_rollout_workspace_bytes(C.byref(r)))
     r.workspace, r.workspace_bytes = ws.data_ptr(), ws.numel()
     with torch.cuda.device(dev):
         check(lib().hk_rollout(C.byref(r), _stream(points)), "hk_rollout")

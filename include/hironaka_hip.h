@@ -92,6 +92,9 @@ extern "C" {
 #define HK_FLAG_FORCE_GENERIC 32u       /* testing: bypass the specialised kernels          */
 #define HK_FLAG_FORCE_TEAM 64u          /* testing: bypass only the register-resident
                                            specialisations (use the four-lanes-per-game kernel) */
+#define HK_FLAG_DEFER_COUNTS 128u       /* hk_rollout: leave the finished-game counts as partial
+                                           sums in `workspace` (they accumulate over launches);
+                                           hk_rollout_reduce_counts adds them to done_count     */
 
 /* ---- fixed policies fused into hk_rollout (jax/players.py) ----------------------------- */
 #define HK_HOST_RANDOM 0    /* players.py:28-39   uniform class id                          */
@@ -142,11 +145,15 @@ typedef struct hk_rollout_desc {
                              an episode restart then costs no device-to-device copy        */
   uint64_t* done_count;   /* [steps+1] or NULL; += #finished games before step 0 and after
                              each step (caller zeroes; accumulates across shards).  Needs
-                             `workspace`: per-workgroup partial counts are written there and
+                             `workspace`: per-workgroup partial counts are added there and
                              summed by a second tiny kernel -- 1024 waves hitting one counter
-                             with atomics would serialise at ~10 ns each                    */
-  void* workspace;        /* device scratch of >= hk_rollout_workspace_bytes(desc) bytes, or
-                             NULL when done_count is NULL; contents need no initialisation  */
+                             with atomics would serialise at ~10 ns each.  With
+                             HK_FLAG_DEFER_COUNTS that second kernel is not launched (and
+                             done_count may be NULL): call hk_rollout_reduce_counts once after
+                             any number of launches that shared the workspace                */
+  void* workspace;        /* device memory of >= hk_rollout_workspace_bytes(desc) bytes, or
+                             NULL when no counts are wanted.  Must be ZERO before its first
+                             use; every reduction leaves it zero again                       */
   uint64_t workspace_bytes;
   void* obs_out;          /* [steps, batch, max_points*dim] or NULL: state before each step */
   int32_t* host_class_out; /* [steps, batch] or NULL: class id chosen by the host          */
@@ -203,9 +210,14 @@ int hk_generate_points(void* points_out, int batch, int max_points, int dim, int
 
 /* ---- fused T-step rollout with in-kernel fixed policies -------------------------------- */
 int hk_rollout(const hk_rollout_desc* desc, void* stream);
-/* bytes of `workspace` hk_rollout needs for this descriptor (0 if done_count is NULL or the
- * descriptor is invalid); depends only on batch, steps, max_points, dim, dtype, flags.      */
+/* bytes of `workspace` hk_rollout needs for this descriptor (0 if the descriptor is invalid);
+ * depends only on batch, steps, max_points, dim, dtype, flags.                               */
 uint64_t hk_rollout_workspace_bytes(const hk_rollout_desc* desc);
+/* done_count[0..steps] += the partial counts that hk_rollout launches with HK_FLAG_DEFER_COUNTS
+ * left in desc->workspace (same batch / steps / max_points / dim / dtype / flags as those
+ * launches); the workspace is zero afterwards.  The counterpart of summing the per-loop
+ * histograms on the host (jax_trainer.py:513,533-534), once instead of after every rollout. */
+int hk_rollout_reduce_counts(const hk_rollout_desc* desc, void* stream);
 
 /* ---- fixed host policy as its own operator: class id per game -------------------------- */
 /* flags: HK_SEM_JAX (default; all ordered pairs, isclose-degenerate pairs skipped, degenerate

@@ -36,7 +36,8 @@ def lib() -> C.CDLL:
         _lib = C.CDLL(_LIB_PATH)
         protos = {}
         for name, (res, args) in A.PROTOTYPES.items():
-            if name in ("hk_abi_version", "hk_strerror", "hk_has_fast_path", "hk_rollout_workspace_bytes"):
+            if name in ("hk_abi_version", "hk_strerror", "hk_has_fast_path", "hk_rollout_workspace_bytes",
+                        "hk_rollout_reduce_counts"):  # launch plumbing: nothing to restate
                 continue
             args = list(args[:-1])  # no stream on the CPU
             protos["hko_" + name[3:]] = (res, args)

@@ -541,3 +541,33 @@ def test_non_finite_and_negative_zero_inputs_take_the_exact_path():
     clean[[5, 70]] = False
     want = CO.step(p, cls, ax, stages=7)["points"]
     assert np.array_equal(outs[0][clean], want[clean])
+
+
+@pytest.mark.parametrize("spec", [(20, 3), (50, 4), (9, 7)])
+def test_deferred_counts_equal_per_launch_counts(spec):
+    """HK_FLAG_DEFER_COUNTS: the per-workgroup partial counts of several launches accumulate in the caller's
+    workspace and one hk_rollout_reduce_counts equals the sum of the per-launch done_counts; the workspace is
+    zero afterwards (fast, team and generic kernels)."""
+    m, d = spec
+    b, T = 3000, 9
+    P = ops.generate_points(b, m, d, 20, seed=11)
+    want = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+    finals = []
+    for k in range(4):
+        Q = P.clone()
+        want += ops.rollout(Q, T, 100 + k)["done_count"]
+        finals.append(Q)
+    ws = ops.rollout_workspace(b, T, spec)
+    assert int(ws.sum()) == 0
+    for k in range(4):
+        Q = P.clone()
+        res = ops.rollout(Q, T, 100 + k, defer_counts=True, workspace=ws)
+        assert "done_count" not in res and torch.equal(Q, finals[k])
+    got = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+    ops.reduce_counts(ws, got, b, T, spec)
+    assert torch.equal(got, want)
+    assert int(ws.sum()) == 0
+    ops.reduce_counts(ws, got, b, T, spec)  # nothing pending: a no-op
+    assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        ops.rollout(P.clone(), T, 1, defer_counts=True)
