@@ -103,6 +103,25 @@ class hk_rollout_desc(C.Structure):
     ]
 
 
+class hk_search_tree(C.Structure):
+    _fields_ = [
+        ("node_visits", C.c_void_p),
+        ("raw_values", C.c_void_p),
+        ("node_values", C.c_void_p),
+        ("parents", C.c_void_p),
+        ("action_from_parent", C.c_void_p),
+        ("children_index", C.c_void_p),
+        ("children_prior_logits", C.c_void_p),
+        ("children_visits", C.c_void_p),
+        ("children_rewards", C.c_void_p),
+        ("children_discounts", C.c_void_p),
+        ("children_values", C.c_void_p),
+        ("batch", C.c_int32),
+        ("num_nodes", C.c_int32),
+        ("num_actions", C.c_int32),
+    ]
+
+
 _vp, _i, _i64, _u32, _u64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64, C.c_double
 
 # name -> (restype, argtypes) of every symbol the header declares.  `stream` is the trailing
@@ -123,6 +142,9 @@ PROTOTYPES = {
     "hk_rollout": (C.c_int, [C.POINTER(hk_rollout_desc), _vp]),
     "hk_rollout_workspace_bytes": (C.c_uint64, [C.POINTER(hk_rollout_desc)]),
     "hk_rollout_reduce_counts": (C.c_int, [C.POINTER(hk_rollout_desc), C.c_void_p]),
+    "hk_search_select": (C.c_int, [C.POINTER(hk_search_tree), _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "hk_search_backup": (C.c_int, [C.POINTER(hk_search_tree), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hk_search_policy": (C.c_int, [C.POINTER(hk_search_tree), _vp, _vp, _vp, _vp, _vp]),
     "hk_zeillinger": (C.c_int, [_vp, _i64, _vp, _i, _i, _i, _i, _u32, _vp]),
     "hk_get_features": (C.c_int, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _d, _vp]),
     "hk_decode_host_class": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),

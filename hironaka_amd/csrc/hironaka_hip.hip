@@ -3,6 +3,7 @@
 // status code.  gfx950 only.
 #include "hk_fast_kernel.h"
 #include "hk_team_kernel.h"
+#include "hk_search.h"
 #include "hk_generic_kernel.h"
 
 using namespace hk;
@@ -373,6 +374,63 @@ int hk_rollout_reduce_counts(const hk_rollout_desc* desc, void* stream) {
   const int wst = counts_workspace(r, grid, &ws);
   if (wst != HK_OK) return wst;
   return launch_count_reduce(ws, (int)grid, r->steps, (unsigned long long*)r->done_count, (hipStream_t)stream);
+}
+
+// ---- search tree operations --------------------------------------------------------------------------
+static int search_tree_from(const hk_search_tree* t, SearchTree& s) {
+  if (!t) return HK_ERR_NULL;
+  if (t->batch < 0 || t->num_nodes < 1 || t->num_actions < 1 || t->num_actions > kSearchMaxActions)
+    return HK_ERR_SHAPE;
+  if (t->batch == 0) {
+    s.batch = 0;
+    return HK_OK;
+  }
+  if (!t->node_visits || !t->raw_values || !t->node_values || !t->parents || !t->action_from_parent ||
+      !t->children_index || !t->children_prior_logits || !t->children_visits || !t->children_rewards ||
+      !t->children_discounts || !t->children_values)
+    return HK_ERR_NULL;
+  s = SearchTree{t->node_visits, t->raw_values, t->node_values, t->parents, t->action_from_parent,
+                 t->children_index, t->children_prior_logits, t->children_visits, t->children_rewards,
+                 t->children_discounts, t->children_values, t->batch, t->num_nodes, t->num_actions};
+  return HK_OK;
+}
+
+int hk_search_select(const hk_search_tree* tree, const float* root_gumbel, const uint8_t* root_invalid,
+                     const int32_t* considered_visits, int max_num_considered_actions, int num_simulations,
+                     int max_depth, int next_free_node, int32_t* parent_out, int32_t* action_out,
+                     int32_t* node_out, void* stream) {
+  SearchTree s{};
+  const int st = search_tree_from(tree, s);
+  if (st != HK_OK) return st;
+  if (s.batch == 0) return HK_OK;
+  if (!root_gumbel || !considered_visits || !parent_out || !action_out || !node_out) return HK_ERR_NULL;
+  if (max_num_considered_actions < 1 || num_simulations < 1 || max_depth < 1 || next_free_node < 1 ||
+      next_free_node >= s.num_nodes || num_simulations + 1 > s.num_nodes)
+    return HK_ERR_SHAPE;
+  return launch_search_select(s, root_gumbel, root_invalid, considered_visits, max_num_considered_actions,
+                              num_simulations, max_depth, next_free_node, parent_out, action_out, node_out,
+                              (hipStream_t)stream);
+}
+
+int hk_search_backup(const hk_search_tree* tree, const int32_t* parent, const int32_t* action,
+                     const int32_t* node, const float* prior_logits, const float* value, const float* reward,
+                     const float* discount, void* stream) {
+  SearchTree s{};
+  const int st = search_tree_from(tree, s);
+  if (st != HK_OK) return st;
+  if (s.batch == 0) return HK_OK;
+  if (!parent || !action || !node || !prior_logits || !value || !reward || !discount) return HK_ERR_NULL;
+  return launch_search_backup(s, parent, action, node, prior_logits, value, reward, discount, (hipStream_t)stream);
+}
+
+int hk_search_policy(const hk_search_tree* tree, const float* root_gumbel, const uint8_t* root_invalid,
+                     int32_t* action_out, float* action_weights_out, void* stream) {
+  SearchTree s{};
+  const int st = search_tree_from(tree, s);
+  if (st != HK_OK) return st;
+  if (s.batch == 0) return HK_OK;
+  if (!root_gumbel || !action_out || !action_weights_out) return HK_ERR_NULL;
+  return launch_search_policy(s, root_gumbel, root_invalid, action_out, action_weights_out, (hipStream_t)stream);
 }
 
 int hk_zeillinger(const void* points, int64_t stride, int32_t* class_out, int batch,

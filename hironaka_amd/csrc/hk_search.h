@@ -1,0 +1,242 @@
+// Tree operations of the batched Gumbel-MuZero search: what the reference gets from
+// `mctx.gumbel_muzero_policy` + `qtransform_completed_by_mix_value(use_mixed_value=True)`
+// (hironaka/jax/simulation_fn.py:85-117).  mctx is a third-party package that is neither vendored nor
+// installed: the algorithm is the published one (Danihelka et al., "Policy improvement by planning with
+// Gumbel", ICLR 2022) and these kernels are pinned to oracle/search_oracle.py -- PARITY UNPINNED against
+// mctx itself.
+//
+// One lane per game walks ITS tree (batch-first arrays, as mctx lays them out and as
+// simulation_fn.py:176-186 reads them back).  A tree of 33 nodes x 4 actions is ~3 KB per game, 25 MB for
+// 8192 games: resident in L2 / MALL, so the lane-strided accesses are cache hits; the environment step
+// and the network evaluation between two tree operations dominate a simulation.
+//
+// Arithmetic contract (shared with the oracle): statistics are float32 and the backward pass is plain
+// float32; whatever feeds an argmax or the final softmax is float64 computed from those statistics.
+#pragma once
+
+#include "hk_common.h"
+
+namespace hk {
+
+constexpr int kSearchMaxActions = 32;
+
+struct SearchTree {
+  int32_t* node_visits;
+  float* raw_values;
+  float* node_values;
+  int32_t* parents;
+  int32_t* action_from_parent;
+  int32_t* children_index;
+  float* children_prior_logits;
+  int32_t* children_visits;
+  float* children_rewards;
+  float* children_discounts;
+  float* children_values;
+  int32_t batch, num_nodes, num_actions;
+};
+
+// completed Q-values of node `n` of game `b` (appendix D of the paper; mctx defaults value_scale = 0.1,
+// maxvisit_init = 50, rescale_values, epsilon = 1e-8) into cq[0..A)
+__device__ inline void search_completed_q(const SearchTree& t, int64_t b, int n, double* cq) {
+  const int A = t.num_actions;
+  const int64_t e0 = (b * t.num_nodes + n) * A;
+  double mx = -INFINITY;
+  for (int a = 0; a < A; ++a) mx = fmax(mx, (double)t.children_prior_logits[e0 + a]);
+  double den = 0.0;
+  for (int a = 0; a < A; ++a) den += exp((double)t.children_prior_logits[e0 + a] - mx);
+  double sum_probs = 0.0, sum_visits = 0.0;
+  int maxvisit = 0;
+  for (int a = 0; a < A; ++a) {
+    const int v = t.children_visits[e0 + a];
+    const double p = fmax(1.1754943508222875e-38, exp((double)t.children_prior_logits[e0 + a] - mx) / den);
+    if (v > 0) sum_probs += p;
+    sum_visits += (double)v;
+    maxvisit = v > maxvisit ? v : maxvisit;
+  }
+  double weighted_q = 0.0;
+  for (int a = 0; a < A; ++a) {
+    const int v = t.children_visits[e0 + a];
+    const double q = (double)t.children_rewards[e0 + a] +
+                     (double)t.children_discounts[e0 + a] * (double)t.children_values[e0 + a];
+    cq[a] = q;
+    if (v > 0) {
+      const double p = fmax(1.1754943508222875e-38, exp((double)t.children_prior_logits[e0 + a] - mx) / den);
+      weighted_q += p * q / sum_probs;
+    }
+  }
+  const double raw = (double)t.raw_values[b * t.num_nodes + n];
+  const double value = (raw + sum_visits * weighted_q) / (sum_visits + 1.0);
+  double lo = INFINITY, hi = -INFINITY;
+  for (int a = 0; a < A; ++a) {
+    if (!(t.children_visits[e0 + a] > 0)) cq[a] = value;
+    lo = fmin(lo, cq[a]);
+    hi = fmax(hi, cq[a]);
+  }
+  const double scale = (50.0 + (double)maxvisit) * 0.1;
+  const double span = fmax(hi - lo, 1e-8);
+  for (int a = 0; a < A; ++a) cq[a] = scale * ((cq[a] - lo) / span);
+}
+
+// Gumbel + logits + completed Q of the root actions whose visit count equals `considered_visit`
+// (sequential halving), -inf for the others; first maximum
+__device__ inline int search_root_argmax(const SearchTree& t, int64_t b, const double* cq, const float* gumbel,
+                                         const uint8_t* invalid, int considered_visit) {
+  const int A = t.num_actions;
+  const int64_t e0 = b * t.num_nodes * A;
+  double mx = -INFINITY;
+  for (int a = 0; a < A; ++a) mx = fmax(mx, (double)t.children_prior_logits[e0 + a]);
+  int best = 0;
+  double best_s = -INFINITY;
+  for (int a = 0; a < A; ++a) {
+    double s = fmax(-1e9, (double)gumbel[b * A + a] + ((double)t.children_prior_logits[e0 + a] - mx) + cq[a]);
+    if (t.children_visits[e0 + a] != considered_visit) s = -INFINITY;
+    if (invalid && invalid[b * A + a]) s = -INFINITY;
+    if (s > best_s) {
+      best_s = s;
+      best = a;
+    }
+  }
+  return best;
+}
+
+// one simulation's descent: the edge (parent, action) to expand and the node index the expansion writes
+// (the existing child at the depth limit, else `next_free`)
+__global__ void search_select_kernel(SearchTree t, const float* gumbel, const uint8_t* invalid,
+                                     const int32_t* table, int max_considered, int num_simulations, int max_depth,
+                                     int next_free, int32_t* parent_out, int32_t* action_out, int32_t* node_out) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= t.batch) return;
+  const int A = t.num_actions;
+  double cq[kSearchMaxActions];
+  // root: sequential halving over the Gumbel-top-k actions
+  search_completed_q(t, b, 0, cq);
+  int num_valid = A, sim_index = 0;
+  for (int a = 0; a < A; ++a) {
+    if (invalid && invalid[b * A + a]) --num_valid;
+    sim_index += t.children_visits[b * t.num_nodes * A + a];
+  }
+  const int num_considered = max_considered < num_valid ? max_considered : num_valid;
+  const int considered_visit = table[(int64_t)num_considered * num_simulations + sim_index];
+  int node = 0;
+  int action = search_root_argmax(t, b, cq, gumbel, invalid, considered_visit);
+  int next = t.children_index[(b * t.num_nodes + node) * A + action];
+  int depth = 0;
+  while (next != -1 && depth + 1 < max_depth) {
+    node = next;
+    ++depth;
+    // interior: argmax(softmax(logits + completed Q) - N / (1 + sum N))
+    search_completed_q(t, b, node, cq);
+    const int64_t e0 = (b * t.num_nodes + node) * A;
+    double mx = -INFINITY, sum_visits = 0.0;
+    for (int a = 0; a < A; ++a) {
+      cq[a] += (double)t.children_prior_logits[e0 + a];
+      mx = fmax(mx, cq[a]);
+      sum_visits += (double)t.children_visits[e0 + a];
+    }
+    double den = 0.0;
+    for (int a = 0; a < A; ++a) den += exp(cq[a] - mx);
+    double best_s = -INFINITY;
+    action = 0;
+    for (int a = 0; a < A; ++a) {
+      const double s = exp(cq[a] - mx) / den - (double)t.children_visits[e0 + a] / (1.0 + sum_visits);
+      if (s > best_s) {
+        best_s = s;
+        action = a;
+      }
+    }
+    next = t.children_index[e0 + action];
+  }
+  parent_out[b] = node;
+  action_out[b] = action;
+  node_out[b] = next == -1 ? next_free : next;
+}
+
+// expansion (the new node's statistics and its edge) + the backward pass to the root
+__global__ void search_backup_kernel(SearchTree t, const int32_t* parent_in, const int32_t* action_in,
+                                     const int32_t* node_in, const float* prior_logits, const float* value,
+                                     const float* reward, const float* discount) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= t.batch) return;
+  const int A = t.num_actions, N = t.num_nodes;
+  const int parent = parent_in[b], action = action_in[b], node = node_in[b];
+  for (int a = 0; a < A; ++a) t.children_prior_logits[(b * N + node) * A + a] = prior_logits[b * A + a];
+  t.raw_values[b * N + node] = value[b];
+  t.node_values[b * N + node] = value[b];
+  t.node_visits[b * N + node] += 1;
+  t.children_index[(b * N + parent) * A + action] = node;
+  t.children_rewards[(b * N + parent) * A + action] = reward[b];
+  t.children_discounts[(b * N + parent) * A + action] = discount[b];
+  t.parents[b * N + node] = parent;
+  t.action_from_parent[b * N + node] = action;
+  int index = node;
+  float leaf_value = value[b];
+  while (index != 0) {
+    const int p = t.parents[b * N + index];
+    const int act = t.action_from_parent[b * N + index];
+    const int64_t e = (b * N + p) * A + act;
+    const float count = (float)t.node_visits[b * N + p];
+    leaf_value = t.children_rewards[e] + t.children_discounts[e] * leaf_value;
+    const float parent_value = (t.node_values[b * N + p] * count + leaf_value) / (count + 1.0f);
+    t.children_values[e] = t.node_values[b * N + index];
+    t.children_visits[e] += 1;
+    t.node_values[b * N + p] = parent_value;
+    t.node_visits[b * N + p] += 1;
+    index = p;
+  }
+}
+
+// the improved policy at the root after the last simulation: action (Gumbel argmax among the most
+// visited) and action_weights = softmax(logits + completed Q)
+__global__ void search_policy_kernel(SearchTree t, const float* gumbel, const uint8_t* invalid, int32_t* action_out,
+                                     float* weights_out) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= t.batch) return;
+  const int A = t.num_actions;
+  const int64_t e0 = b * t.num_nodes * A;
+  double cq[kSearchMaxActions];
+  search_completed_q(t, b, 0, cq);
+  int maxvisit = 0;
+  for (int a = 0; a < A; ++a) maxvisit = t.children_visits[e0 + a] > maxvisit ? t.children_visits[e0 + a] : maxvisit;
+  action_out[b] = search_root_argmax(t, b, cq, gumbel, invalid, maxvisit);
+  double mx = -INFINITY;
+  for (int a = 0; a < A; ++a) {
+    cq[a] += (double)t.children_prior_logits[e0 + a];
+    mx = fmax(mx, cq[a]);
+  }
+  if (invalid)
+    for (int a = 0; a < A; ++a) cq[a] = invalid[b * A + a] ? -3.4028234663852886e38 : cq[a] - mx;
+  mx = -INFINITY;
+  for (int a = 0; a < A; ++a) mx = fmax(mx, cq[a]);
+  double den = 0.0;
+  for (int a = 0; a < A; ++a) den += exp(cq[a] - mx);
+  for (int a = 0; a < A; ++a) weights_out[b * A + a] = (float)(exp(cq[a] - mx) / den);
+}
+
+inline int launch_search_select(const SearchTree& t, const float* gumbel, const uint8_t* invalid,
+                                const int32_t* table, int max_considered, int num_simulations, int max_depth,
+                                int next_free, int32_t* parent_out, int32_t* action_out, int32_t* node_out,
+                                hipStream_t stream) {
+  launch_prepare();
+  hipLaunchKernelGGL(search_select_kernel, dim3((t.batch + 255) / 256), dim3(256), 0, stream, t, gumbel, invalid,
+                     table, max_considered, num_simulations, max_depth, next_free, parent_out, action_out, node_out);
+  return launch_status();
+}
+
+inline int launch_search_backup(const SearchTree& t, const int32_t* parent, const int32_t* action, const int32_t* node,
+                                const float* prior_logits, const float* value, const float* reward,
+                                const float* discount, hipStream_t stream) {
+  launch_prepare();
+  hipLaunchKernelGGL(search_backup_kernel, dim3((t.batch + 255) / 256), dim3(256), 0, stream, t, parent, action, node,
+                     prior_logits, value, reward, discount);
+  return launch_status();
+}
+
+inline int launch_search_policy(const SearchTree& t, const float* gumbel, const uint8_t* invalid, int32_t* action_out,
+                                float* weights_out, hipStream_t stream) {
+  launch_prepare();
+  hipLaunchKernelGGL(search_policy_kernel, dim3((t.batch + 255) / 256), dim3(256), 0, stream, t, gumbel, invalid,
+                     action_out, weights_out);
+  return launch_status();
+}
+
+}  // namespace hk

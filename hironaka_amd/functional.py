@@ -165,3 +165,23 @@ def rollout_sanity_tests(rollout: Rollout, spec: Tuple[int, int]) -> bool:
     if torch.isclose(sums, torch.ones_like(sums)).all() and ((policy <= 1.0) & (policy >= 0.0)).all():
         return False
     return True
+
+
+def get_dynamic_policy_fn(spec: Tuple[int, int], host_fn: Callable, agent_fn: Callable) -> Callable:
+    """jax/util.py:217-258 -- the policy of a role-agnostic tree: states are [B, (m+1)*d]; a host state
+    has a zero tail, an agent state carries its subset mask there.  As in the reference the choice is made
+    ONCE per batch (host if any state of the batch is a host state); agent logits are padded with -inf to
+    the host's action count."""
+    _, coords_preprocess = get_preprocess_fns("agent", spec)
+    extra_action_dim = 2 ** spec[1] - 2 * spec[1] - 1
+
+    def dynamic_policy_fn(state, host_and_agent_args, *args, **kwargs):
+        host_args, agent_args = host_and_agent_args
+        coord = coords_preprocess(state, None)
+        use_host = bool(torch.isclose(coord, torch.zeros((), device=coord.device, dtype=coord.dtype)).all(dim=-1).any())
+        if use_host:
+            return host_fn(state, *host_args, *args, **kwargs)
+        policy, value = agent_fn(state, *agent_args, *args, **kwargs)
+        return torch.nn.functional.pad(policy, (0, extra_action_dim), value=float("-inf")), value
+
+    return dynamic_policy_fn

@@ -219,6 +219,50 @@ uint64_t hk_rollout_workspace_bytes(const hk_rollout_desc* desc);
  * histograms on the host (jax_trainer.py:513,533-534), once instead of after every rollout. */
 int hk_rollout_reduce_counts(const hk_rollout_desc* desc, void* stream);
 
+/* ---- tree operations of the batched Gumbel-MuZero search --------------------
+ * Replaces the calls into the third-party `mctx` package at hironaka/jax/simulation_fn.py:85-117
+ * (`mctx.gumbel_muzero_policy`, qtransform_completed_by_mix_value(use_mixed_value=True)); the arrays
+ * are mctx's `Tree` fields with the same names, batch-first, which simulation_fn.py:176-186 reads back
+ * (node_values[:, 0], children_index[:, 0, :], embeddings).  Embeddings stay with the caller.
+ * num_nodes = num_simulations + 1; node 0 is the root; children_index == -1 means unvisited.
+ * One search = initialise the arrays (root statistics at node 0, node_visits[:, 0] = 1), then
+ * num_simulations x { hk_search_select -> caller runs recurrent_fn on (parent embedding, action) ->
+ * hk_search_backup }, then hk_search_policy.                                                      */
+typedef struct hk_search_tree {
+  int32_t* node_visits;         /* [B, N]    */
+  float* raw_values;            /* [B, N]    */
+  float* node_values;           /* [B, N]    */
+  int32_t* parents;             /* [B, N]    */
+  int32_t* action_from_parent;  /* [B, N]    */
+  int32_t* children_index;      /* [B, N, A] */
+  float* children_prior_logits; /* [B, N, A] */
+  int32_t* children_visits;     /* [B, N, A] */
+  float* children_rewards;      /* [B, N, A] */
+  float* children_discounts;    /* [B, N, A] */
+  float* children_values;       /* [B, N, A] */
+  int32_t batch, num_nodes, num_actions; /* num_actions <= 32 */
+} hk_search_tree;
+
+/* One simulation's descent (root: Gumbel + sequential halving; below: argmax(pi' - N/(1+sum N))):
+ * parent_out/action_out [B] = the edge to expand, node_out [B] = the node index the expansion writes
+ * (`next_free_node` for an unvisited edge, the existing child when max_depth stopped the descent).
+ * root_gumbel [B, A] = gumbel_scale * Gumbel(0,1) noise (caller draws it); root_invalid [B, A] u8 or
+ * NULL; considered_visits [max_num_considered_actions + 1, num_simulations] i32 = the sequential
+ * halving schedule (hironaka_amd.search.get_table_of_considered_visits).                          */
+int hk_search_select(const hk_search_tree* tree, const float* root_gumbel, const uint8_t* root_invalid,
+                     const int32_t* considered_visits, int max_num_considered_actions, int num_simulations,
+                     int max_depth, int next_free_node, int32_t* parent_out, int32_t* action_out,
+                     int32_t* node_out, void* stream);
+/* Expansion + backward pass: writes the new node's statistics (prior_logits [B, A], value [B]) and
+ * its edge (reward, discount [B]) and updates values / visit counts up to the root.              */
+int hk_search_backup(const hk_search_tree* tree, const int32_t* parent, const int32_t* action,
+                     const int32_t* node, const float* prior_logits, const float* value,
+                     const float* reward, const float* discount, void* stream);
+/* After the last simulation: action_out [B] (the Gumbel argmax among the most visited root actions)
+ * and action_weights_out [B, A] = softmax(root logits + completed Q-values).                      */
+int hk_search_policy(const hk_search_tree* tree, const float* root_gumbel, const uint8_t* root_invalid,
+                     int32_t* action_out, float* action_weights_out, void* stream);
+
 /* ---- fixed host policy as its own operator: class id per game -------------------------- */
 /* flags: HK_SEM_JAX (default; all ordered pairs, isclose-degenerate pairs skipped, degenerate
  * game -> class 0) or HK_SEM_LIST (host.py:70-95: pairs i<j of the available rows in row order,

@@ -37,7 +37,8 @@ def lib() -> C.CDLL:
         protos = {}
         for name, (res, args) in A.PROTOTYPES.items():
             if name in ("hk_abi_version", "hk_strerror", "hk_has_fast_path", "hk_rollout_workspace_bytes",
-                        "hk_rollout_reduce_counts"):  # launch plumbing: nothing to restate
+                        "hk_rollout_reduce_counts", "hk_search_select", "hk_search_backup",
+                        "hk_search_policy"):  # launch plumbing / restated in oracle/search_oracle.py
                 continue
             args = list(args[:-1])  # no stream on the CPU
             protos["hko_" + name[3:]] = (res, args)

@@ -38,7 +38,8 @@ def test_descriptor_layout_matches_c():
     """sizeof/offsetof as the C compiler sees them (gcc on the header) == ctypes."""
     import subprocess, tempfile
     fields = {"hk_step_desc": [f[0] for f in A.hk_step_desc._fields_],
-              "hk_rollout_desc": [f[0] for f in A.hk_rollout_desc._fields_]}
+              "hk_rollout_desc": [f[0] for f in A.hk_rollout_desc._fields_],
+              "hk_search_tree": [f[0] for f in A.hk_search_tree._fields_]}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "hironaka_hip.h"', 'int main(){']
     for st, fl in fields.items():
         src.append(f'printf("{st} %zu\\n", sizeof({st}));')
@@ -52,7 +53,8 @@ def test_descriptor_layout_matches_c():
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         out = subprocess.check_output([exe]).decode().split("\n")
     got = dict(line.split() for line in out if line)
-    for st, cls in (("hk_step_desc", A.hk_step_desc), ("hk_rollout_desc", A.hk_rollout_desc)):
+    for st, cls in (("hk_step_desc", A.hk_step_desc), ("hk_rollout_desc", A.hk_rollout_desc),
+                    ("hk_search_tree", A.hk_search_tree)):
         assert int(got[st]) == ctypes.sizeof(cls)
         for f in fields[st]:
             assert int(got[f"{st}.{f}"]) == getattr(cls, f).offset, (st, f)
