@@ -157,3 +157,21 @@ def rollout_postprocess(rollouts, role: str, dimension: int, discount: float = 0
     num_points = (obs >= 0).sum(dim=-1) // dimension - offset
     new_value = calculate_value_using_reward_fn(num_points, discount, role, use_unified_tree).to(value.dtype)
     return obs.reshape(-1, obs.shape[2]), policy.reshape(-1, policy.shape[2]), new_value.reshape(-1)
+
+
+def select_sample_after_sim(role: str, rollout, dimension: int, mix_random_terminal_states: bool = True,
+                            key: Optional[int] = None) -> torch.Tensor:
+    """jax/util.py:351-382 -- mask [sample_size] of the samples kept for training: every state of an
+    unfinished game, plus (optionally) as many uniformly chosen samples as there are unfinished ones
+    (a random permutation of the indices, those ranked below the number of unfinished states), so that
+    terminal states are mixed in at no more than 1:1.  `key`: int seed of the permutation (None: time)."""
+    obs = rollout[0]
+    size = obs.shape[0]
+    offset = dimension if role == "agent" else 0
+    undone_idx = (obs >= 0).sum(dim=-1) > (dimension + offset)
+    if not mix_random_terminal_states:
+        return undone_idx
+    import time
+    gen = torch.Generator(device=obs.device).manual_seed(int(time.time_ns() if key is None else key) % (1 << 63))
+    random_idx = torch.randperm(size, generator=gen, device=obs.device)
+    return undone_idx | (random_idx < undone_idx.sum())

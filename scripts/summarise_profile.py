@@ -44,7 +44,7 @@ if trace:
     lines.append("kernel,grid_threads,calls,mean_us,p50_us,p95_us")
     for (k, grid), v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
         v = np.array(v)
-        if "fast_kernel" in k and ", 1>" in k:  # rollout mode
+        if "fast_kernel<" in k and k.split("<")[1].split(",")[2].strip(" >") == "1":  # rollout mode
             big, small = split_rollout(v)
             parts = (("T=20 episodes", big), ("T=1 steps", small))
         else:
@@ -75,9 +75,9 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     for r in csv.DictReader(open(f[0])):
         if r["Grid_Size"] != HEADLINE_GRID:
             continue
-        if "fast_kernel<20, 3, 1>" in r["Kernel_Name"]:
+        if "fast_kernel<20, 3, 1" in r["Kernel_Name"]:
             e = roll[r["Dispatch_Id"]]
-        elif "fast_kernel<20, 3, 0>" in r["Kernel_Name"]:
+        elif "fast_kernel<20, 3, 0" in r["Kernel_Name"]:
             e = step[r["Dispatch_Id"]]
         else:
             continue

@@ -21,7 +21,7 @@ from hironaka_amd.players import (all_coord_host_fn, choose_first_agent_fn, choo
                                   zeillinger_fn_slice)
 from hironaka_amd.recurrent_fn import get_recurrent_fn_for_role, get_unified_recurrent_fn
 from hironaka_amd.rollout import (compute_rho, details_from_done_counts, rho_from_details, rollout_postprocess,
-                                  simulate_fixed_policies)
+                                  select_sample_after_sim, simulate_fixed_policies)
 from oracle import c_oracle as CO
 from oracle import np_oracle as NO
 
@@ -412,3 +412,19 @@ def test_rollout_postprocess_reference_vectors_on_device():
         rollouts = (obs, torch.zeros(b, t, 4, device="cuda"), torch.zeros(b, t, device="cuda"))
         _, _, v = rollout_postprocess(rollouts, case["role"], doc["dimension"], doc["discount"], case["unified"])
         assert np.allclose(host(v), np.asarray(case["expected"], np.float32).ravel(), rtol=0, atol=1e-6)
+
+
+def test_select_sample_after_sim():
+    """jax/util.py:351-382: unfinished states are always kept; with mixing, exactly as many extra draws as
+    there are unfinished states (so at most twice their number in total)"""
+    spec, b, T = (20, 3), 256, 20
+    for role, extra in (("host", 0), ("agent", 3)):
+        obs, policy, value = simulate_fixed_policies(5, role, spec=spec, batch_size=b, max_value=20, max_length_game=T)
+        undone = (obs >= 0).sum(-1) > 3 + extra
+        plain = select_sample_after_sim(role, (obs, policy, value), 3, mix_random_terminal_states=False)
+        assert torch.equal(plain, undone)
+        mixed = select_sample_after_sim(role, (obs, policy, value), 3, key=9)
+        n = int(undone.sum())
+        assert bool((mixed | ~undone).all()) and n <= int(mixed.sum()) <= 2 * n
+        assert torch.equal(mixed, select_sample_after_sim(role, (obs, policy, value), 3, key=9))
+        assert 0 < n < b * T
