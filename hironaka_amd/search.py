@@ -131,32 +131,20 @@ def _mask_invalid_actions(logits: torch.Tensor, invalid_actions: Optional[torch.
     return torch.where(invalid_actions.bool(), torch.full_like(logits, torch.finfo(logits.dtype).min), logits)
 
 
-def gumbel_muzero_policy(params, rng_key, root: RootFnOutput, recurrent_fn: Callable, num_simulations: int,
-                         invalid_actions: Optional[torch.Tensor] = None, max_depth: Optional[int] = None, *,
-                         max_num_considered_actions: int = 16, gumbel_scale: float = 1.0,
-                         gumbel: Optional[torch.Tensor] = None) -> PolicyOutput:
-    """rng_key: int seed or torch.Generator for the root Gumbel noise (or pass `gumbel` [B, A], already
-    scaled).  recurrent_fn(params, rng_key, action [B] int64, embedding [B, E]) ->
-    (RecurrentFnOutput(reward, discount, prior_logits, value), next_embedding)."""
-    if not root.prior_logits.is_cuda:
-        raise ValueError("the search runs on the HIP device: root tensors must be on the GPU")
+def _draw_gumbel(rng_key, shape, gumbel_scale: float, dev) -> torch.Tensor:
+    gen = rng_key if isinstance(rng_key, torch.Generator) else torch.Generator(device=dev).manual_seed(int(rng_key))
+    u = torch.rand(shape, generator=gen, device=dev, dtype=torch.float32).clamp_(min=1e-20, max=1.0 - 1e-7)
+    return -torch.log(-torch.log(u)) * gumbel_scale
+
+
+def _run_search(params, rng_key, root: RootFnOutput, gumbel: torch.Tensor, invalid_u8: Optional[torch.Tensor],
+                table: torch.Tensor, recurrent_fn: Callable, num_simulations: int, max_depth: int,
+                max_num_considered_actions: int) -> PolicyOutput:
+    """the device work of one search (no host synchronisation, no host-to-device copies: capturable)"""
     b, a = root.prior_logits.shape
-    if a > 32:
-        raise ValueError("at most 32 actions")
     dev = root.prior_logits.device
-    max_depth = num_simulations if max_depth is None else max_depth
-    invalid_u8 = None if invalid_actions is None else invalid_actions.to(torch.uint8).contiguous()
-    root = RootFnOutput(_mask_invalid_actions(root.prior_logits.to(torch.float32), invalid_actions).contiguous(),
-                        root.value.to(torch.float32).contiguous(), root.embedding.contiguous())
-    if gumbel is None:
-        gen = rng_key if isinstance(rng_key, torch.Generator) else torch.Generator(device=dev).manual_seed(int(rng_key))
-        u = torch.rand((b, a), generator=gen, device=dev, dtype=torch.float32).clamp_(min=1e-20, max=1.0 - 1e-7)
-        gumbel = -torch.log(-torch.log(u)) * gumbel_scale
-    gumbel = gumbel.to(torch.float32).contiguous()
     tree = instantiate_tree_from_root(root, num_simulations, invalid_u8)
     desc = _tree_desc(tree)
-    table = torch.tensor(get_table_of_considered_visits(max_num_considered_actions, num_simulations),
-                         dtype=torch.int32, device=dev).reshape(max_num_considered_actions + 1, num_simulations)
     parent = torch.empty(b, dtype=torch.int32, device=dev)
     action = torch.empty(b, dtype=torch.int32, device=dev)
     node = torch.empty(b, dtype=torch.int32, device=dev)
@@ -185,3 +173,92 @@ def gumbel_muzero_policy(params, rng_key, root: RootFnOutput, recurrent_fn: Call
         check(L.hk_search_policy(C.byref(desc), gumbel.data_ptr(), inv_ptr, final_action.data_ptr(),
                                  weights.data_ptr(), _stream(gumbel)), "hk_search_policy")
     return PolicyOutput(action=final_action.long(), action_weights=weights, search_tree=tree)
+
+
+def _considered_visits_table(max_num_considered_actions: int, num_simulations: int, dev) -> torch.Tensor:
+    return torch.tensor(get_table_of_considered_visits(max_num_considered_actions, num_simulations),
+                        dtype=torch.int32, device=dev).reshape(max_num_considered_actions + 1, num_simulations)
+
+
+def gumbel_muzero_policy(params, rng_key, root: RootFnOutput, recurrent_fn: Callable, num_simulations: int,
+                         invalid_actions: Optional[torch.Tensor] = None, max_depth: Optional[int] = None, *,
+                         max_num_considered_actions: int = 16, gumbel_scale: float = 1.0,
+                         gumbel: Optional[torch.Tensor] = None) -> PolicyOutput:
+    """rng_key: int seed or torch.Generator for the root Gumbel noise (or pass `gumbel` [B, A], already
+    scaled).  recurrent_fn(params, rng_key, action [B] int64, embedding [B, E]) ->
+    (RecurrentFnOutput(reward, discount, prior_logits, value), next_embedding)."""
+    if not root.prior_logits.is_cuda:
+        raise ValueError("the search runs on the HIP device: root tensors must be on the GPU")
+    b, a = root.prior_logits.shape
+    if a > 32:
+        raise ValueError("at most 32 actions")
+    dev = root.prior_logits.device
+    max_depth = num_simulations if max_depth is None else max_depth
+    invalid_u8 = None if invalid_actions is None else invalid_actions.to(torch.uint8).contiguous()
+    root = RootFnOutput(_mask_invalid_actions(root.prior_logits.to(torch.float32), invalid_actions).contiguous(),
+                        root.value.to(torch.float32).contiguous(), root.embedding.contiguous())
+    if gumbel is None:
+        gumbel = _draw_gumbel(rng_key, (b, a), gumbel_scale, dev)
+    gumbel = gumbel.to(torch.float32).contiguous()
+    table = _considered_visits_table(max_num_considered_actions, num_simulations, dev)
+    return _run_search(params, rng_key, root, gumbel, invalid_u8, table, recurrent_fn, num_simulations, max_depth,
+                       max_num_considered_actions)
+
+
+class CapturedSearch:
+    """One search of fixed shapes and fixed callables captured into a hipGraph: ~35 small launches per
+    simulation (tree kernels, gathers, the opponent, the HIP step, the network) are replayed as one graph
+    instead of being issued one by one from Python.
+
+    Requirements on `recurrent_fn` (and what it calls): no host synchronisation, no host-to-device copies,
+    random numbers only from torch's default generator (which graphs advance correctly) -- e.g. the fixed
+    policies of `players.py` with `key=None`.  `params` are captured by reference: update weights in place.
+    The returned PolicyOutput lives in the graph's memory and is overwritten by the next call."""
+
+    def __init__(self, params, rng_key, root: RootFnOutput, recurrent_fn: Callable, num_simulations: int,
+                 invalid_actions: Optional[torch.Tensor] = None, max_depth: Optional[int] = None, *,
+                 max_num_considered_actions: int = 16, gumbel_scale: float = 1.0):
+        b, a = root.prior_logits.shape
+        dev = root.prior_logits.device
+        self.gumbel_scale = gumbel_scale
+        self.has_invalid = invalid_actions is not None
+        self.logits = torch.zeros((b, a), dtype=torch.float32, device=dev)
+        self.value = torch.zeros(b, dtype=torch.float32, device=dev)
+        self.embedding = torch.zeros_like(root.embedding).contiguous()
+        self.gumbel = torch.zeros((b, a), dtype=torch.float32, device=dev)
+        self.invalid = torch.zeros((b, a), dtype=torch.uint8, device=dev) if self.has_invalid else None
+        max_depth = num_simulations if max_depth is None else max_depth
+        # everything the graph reads from outside its own memory pool must outlive it
+        self.table = table = _considered_visits_table(max_num_considered_actions, num_simulations, dev)
+        self.params, self.recurrent_fn = params, recurrent_fn
+        self._fill(root, invalid_actions, rng_key)
+
+        def run():
+            return _run_search(params, None, RootFnOutput(self.logits, self.value, self.embedding), self.gumbel,
+                               self.invalid, table, recurrent_fn, num_simulations, max_depth,
+                               max_num_considered_actions)
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            run()  # warm-up outside the capture (lazy initialisations, workspace allocations)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = run()
+
+    def _fill(self, root: RootFnOutput, invalid_actions, rng_key):
+        self.logits.copy_(_mask_invalid_actions(root.prior_logits.to(torch.float32), invalid_actions))
+        self.value.copy_(root.value)
+        self.embedding.copy_(root.embedding)
+        self.gumbel.copy_(_draw_gumbel(rng_key, tuple(self.gumbel.shape), self.gumbel_scale, self.gumbel.device))
+        if self.has_invalid:
+            self.invalid.copy_(invalid_actions)
+
+    def __call__(self, rng_key, root: RootFnOutput, invalid_actions: Optional[torch.Tensor] = None) -> PolicyOutput:
+        if (invalid_actions is not None) != self.has_invalid:
+            raise ValueError("this search was captured with" + ("" if self.has_invalid else "out") + " an action mask")
+        self._fill(root, invalid_actions, rng_key)
+        self.graph.replay()
+        return self.out

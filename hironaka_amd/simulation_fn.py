@@ -15,7 +15,7 @@ import torch
 
 from .functional import get_dynamic_policy_fn
 from .recurrent_fn import get_recurrent_fn_for_role, get_unified_recurrent_fn
-from .search import PolicyOutput, RootFnOutput, gumbel_muzero_policy
+from .search import CapturedSearch, PolicyOutput, RootFnOutput, gumbel_muzero_policy
 
 
 def _split(key: int, n: int = 2):
@@ -27,9 +27,12 @@ def get_evaluation_loop(role: str, policy_fn: Callable, opponent_fn: Callable, r
                         spec: Tuple[int, int], num_evaluations: int, max_depth: int,
                         max_num_considered_actions: int, discount: float, rescale_points: bool, reposition: bool,
                         role_agnostic: Optional[bool] = None, gumbel_scale: Optional[float] = 0.3,
-                        dtype=torch.float32) -> Callable:
+                        dtype=torch.float32, use_graph: bool = False) -> Callable:
     """simulation_fn.py:16-122.  policy_fn(observations, *args, key=) -> (policy_prior, value_prior);
-    opponent_fn(observations, *args, key=) -> one-hot actions; reward_fn(dones, prev_dones) -> rewards."""
+    opponent_fn(observations, *args, key=) -> one-hot actions; reward_fn(dones, prev_dones) -> rewards.
+    use_graph (not in the reference): capture the search of each distinct batch shape into a hipGraph
+    (search.CapturedSearch: its requirements apply -- role-specific trees only, callables without host
+    synchronisation, randomness from torch's default generator, same argument objects on every call)."""
     if role_agnostic:
         policy_fn_on_root = get_dynamic_policy_fn(spec, policy_fn, opponent_fn)
         recurrent_fn = get_unified_recurrent_fn(policy_fn, opponent_fn, reward_fn, spec, discount=discount,
@@ -42,12 +45,25 @@ def get_evaluation_loop(role: str, policy_fn: Callable, opponent_fn: Callable, r
         recurrent_fn = get_recurrent_fn_for_role(role, policy_fn, opponent_fn, reward_fn, spec, discount=discount,
                                                  dtype=dtype, rescale_points=rescale_points, reposition=reposition)
 
+    if use_graph and role_agnostic:
+        raise ValueError("the role-agnostic tree decides host/agent on the host per call: not capturable")
+    captured = {}
+
     def evaluation_loop(key: int, root_states: torch.Tensor, role_fn_args=(), opponent_fn_args=(),
                         invalid_actions=None) -> PolicyOutput:
         key, subkey = _split(key)
         policy_prior, value_prior = policy_fn_on_root(root_states, (role_fn_args, opponent_fn_args), key=subkey)
         root = RootFnOutput(prior_logits=policy_prior, value=value_prior, embedding=root_states)
         key, subkey = _split(key)
+        if use_graph:
+            sig = (tuple(root_states.shape), root_states.dtype, root_states.device, invalid_actions is not None,
+                   id(role_fn_args), id(opponent_fn_args))
+            if sig not in captured:
+                captured[sig] = CapturedSearch((role_fn_args, opponent_fn_args), subkey, root, recurrent_fn,
+                                               num_evaluations, invalid_actions, max_depth,
+                                               max_num_considered_actions=max_num_considered_actions,
+                                               gumbel_scale=gumbel_scale)
+            return captured[sig](subkey, root, invalid_actions)
         return gumbel_muzero_policy(params=(role_fn_args, opponent_fn_args), rng_key=subkey, root=root,
                                     recurrent_fn=recurrent_fn, num_simulations=num_evaluations,
                                     invalid_actions=invalid_actions, max_depth=max_depth,

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--sims", type=int, default=32)
     ap.add_argument("--moves", type=int, default=20)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--eager", action="store_true", help="issue every launch from Python instead of replaying a hipGraph")
     args = ap.parse_args()
     m, d = 20, 3
     spec = (m, d)
@@ -38,10 +39,10 @@ def main():
         h = torch.relu((obs.clamp(min=-1.0) / 20.0) @ w1) @ w2
         return h[:, :ncls].contiguous(), torch.tanh(h[:, ncls]).contiguous()
 
-    opponent = lambda obs, *a, key=0, **kw: random_agent_fn(obs, spec, key=key)
+    opponent = lambda obs, *a, key=0, **kw: random_agent_fn(obs, spec, key=None)  # default generator: capturable
     ev = get_evaluation_loop("host", policy_fn, opponent, get_reward_fn("host"), spec, num_evaluations=args.sims,
                              max_depth=args.moves, max_num_considered_actions=ncls, discount=0.99,
-                             rescale_points=False, reposition=True)
+                             rescale_points=False, reposition=True, use_graph=not args.eager)
     sim = get_simulation("host", ev, args.batch, m, d, args.moves)
     root = generate_pts(1, (args.batch, m, d), 20, torch.float32, False, True).reshape(args.batch, m * d)
     sim(0, root)  # warm-up
@@ -56,6 +57,7 @@ def main():
         "workload": f"simulate(): dim={d}, max_points={m}, batch={args.batch}, {args.sims} simulations/move, "
                     f"{args.moves} moves (BASELINE configs[4]); host role vs random agent",
         "policy_network": "stand-in: fixed random MLP 60-256-5 (the reference's networks are out of scope)",
+        "launches": "eager" if args.eager else "one hipGraph per search (32 simulations)",
         "seconds_per_simulate": dt,
         "env_steps_in_search_per_s": env_steps / dt,
         "searches_per_s": args.batch * args.moves / dt,

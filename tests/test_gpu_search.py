@@ -139,3 +139,29 @@ def test_simulation_shapes_and_sanity():
     assert bool((tails[:, 0::2].abs().sum(-1) == 0).all())  # host states at even plies
     assert bool((tails[:, 1::2].sum(-1) >= 2).all())        # agent states carry a subset of >= 2 coordinates
     assert rollout_sanity_tests((obs.reshape(b * T, -1), logp.reshape(b * T, -1), value.reshape(-1)), spec)
+
+
+def test_captured_search_equals_eager():
+    """the same search replayed from a hipGraph (CapturedSearch) gives the eager result, call after call"""
+    from hironaka_amd.search import CapturedSearch
+    spec, b, n = (20, 3), 128, 16
+    m, d = spec
+    ncls = 2 ** d - d - 1
+    policy_fn = _mlp(m * d, ncls, 8)
+    opponent = lambda obs, *a, key=0, **kw: choose_first_agent_fn(obs, spec)  # deterministic, capturable
+    rf = get_recurrent_fn_for_role("host", policy_fn, opponent, get_reward_fn("host"), spec, discount=0.99,
+                                   rescale_points=False, reposition=True)
+    cap = None
+    for seed in (1, 2, 3):
+        root_state = generate_pts(seed, (b, m, d), 20, torch.float32, False, True).reshape(b, m * d)
+        logits, value = policy_fn(root_state)
+        root = RootFnOutput(logits, value, root_state)
+        if cap is None:
+            cap = CapturedSearch(((), ()), 5, root, rf, n, max_depth=10, max_num_considered_actions=4, gumbel_scale=0.3)
+        got = cap(100 + seed, root)
+        want = gumbel_muzero_policy(((), ()), 100 + seed, root, rf, n, max_depth=10, max_num_considered_actions=4,
+                                    gumbel_scale=0.3)
+        assert torch.equal(got.action, want.action)
+        assert torch.equal(got.action_weights, want.action_weights)
+        for name in ("node_visits", "children_index", "children_visits", "node_values", "embeddings"):
+            assert torch.equal(getattr(got.search_tree, name), getattr(want.search_tree, name)), name
