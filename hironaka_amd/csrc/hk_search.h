@@ -36,80 +36,103 @@ struct SearchTree {
 };
 
 // completed Q-values of node `n` of game `b` (appendix D of the paper; mctx defaults value_scale = 0.1,
-// maxvisit_init = 50, rescale_values, epsilon = 1e-8) into cq[0..A)
-__device__ inline void search_completed_q(const SearchTree& t, int64_t b, int n, double* cq) {
+// maxvisit_init = 50, rescale_values, epsilon = 1e-8) into cq[0..A).  AMAX = compile-time bound of the
+// action count: the per-action arrays live in registers and every exp() is evaluated once.
+template <int AMAX>
+__device__ inline void search_completed_q(const SearchTree& t, int64_t b, int n, double (&cq)[AMAX]) {
   const int A = t.num_actions;
   const int64_t e0 = (b * t.num_nodes + n) * A;
+  double logit[AMAX], p[AMAX];
+  int visits[AMAX];
   double mx = -INFINITY;
-  for (int a = 0; a < A; ++a) mx = fmax(mx, (double)t.children_prior_logits[e0 + a]);
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a)
+    if (a < A) {
+      logit[a] = (double)t.children_prior_logits[e0 + a];
+      visits[a] = t.children_visits[e0 + a];
+      cq[a] = (double)t.children_rewards[e0 + a] +
+              (double)t.children_discounts[e0 + a] * (double)t.children_values[e0 + a];
+      mx = fmax(mx, logit[a]);
+    }
   double den = 0.0;
-  for (int a = 0; a < A; ++a) den += exp((double)t.children_prior_logits[e0 + a] - mx);
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a)
+    if (a < A) {
+      p[a] = exp(logit[a] - mx);
+      den += p[a];
+    }
   double sum_probs = 0.0, sum_visits = 0.0;
   int maxvisit = 0;
-  for (int a = 0; a < A; ++a) {
-    const int v = t.children_visits[e0 + a];
-    const double p = fmax(1.1754943508222875e-38, exp((double)t.children_prior_logits[e0 + a] - mx) / den);
-    if (v > 0) sum_probs += p;
-    sum_visits += (double)v;
-    maxvisit = v > maxvisit ? v : maxvisit;
-  }
-  double weighted_q = 0.0;
-  for (int a = 0; a < A; ++a) {
-    const int v = t.children_visits[e0 + a];
-    const double q = (double)t.children_rewards[e0 + a] +
-                     (double)t.children_discounts[e0 + a] * (double)t.children_values[e0 + a];
-    cq[a] = q;
-    if (v > 0) {
-      const double p = fmax(1.1754943508222875e-38, exp((double)t.children_prior_logits[e0 + a] - mx) / den);
-      weighted_q += p * q / sum_probs;
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a)
+    if (a < A) {
+      p[a] = fmax(1.1754943508222875e-38, p[a] / den);
+      if (visits[a] > 0) sum_probs += p[a];
+      sum_visits += (double)visits[a];
+      maxvisit = visits[a] > maxvisit ? visits[a] : maxvisit;
     }
-  }
+  double weighted_q = 0.0;
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a)
+    if (a < A && visits[a] > 0) weighted_q += p[a] * cq[a] / sum_probs;
   const double raw = (double)t.raw_values[b * t.num_nodes + n];
   const double value = (raw + sum_visits * weighted_q) / (sum_visits + 1.0);
   double lo = INFINITY, hi = -INFINITY;
-  for (int a = 0; a < A; ++a) {
-    if (!(t.children_visits[e0 + a] > 0)) cq[a] = value;
-    lo = fmin(lo, cq[a]);
-    hi = fmax(hi, cq[a]);
-  }
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a)
+    if (a < A) {
+      if (!(visits[a] > 0)) cq[a] = value;
+      lo = fmin(lo, cq[a]);
+      hi = fmax(hi, cq[a]);
+    }
   const double scale = (50.0 + (double)maxvisit) * 0.1;
   const double span = fmax(hi - lo, 1e-8);
-  for (int a = 0; a < A; ++a) cq[a] = scale * ((cq[a] - lo) / span);
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a)
+    if (a < A) cq[a] = scale * ((cq[a] - lo) / span);
 }
 
 // Gumbel + logits + completed Q of the root actions whose visit count equals `considered_visit`
 // (sequential halving), -inf for the others; first maximum
-__device__ inline int search_root_argmax(const SearchTree& t, int64_t b, const double* cq, const float* gumbel,
+template <int AMAX>
+__device__ inline int search_root_argmax(const SearchTree& t, int64_t b, const double (&cq)[AMAX], const float* gumbel,
                                          const uint8_t* invalid, int considered_visit) {
   const int A = t.num_actions;
   const int64_t e0 = b * t.num_nodes * A;
   double mx = -INFINITY;
-  for (int a = 0; a < A; ++a) mx = fmax(mx, (double)t.children_prior_logits[e0 + a]);
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a)
+    if (a < A) mx = fmax(mx, (double)t.children_prior_logits[e0 + a]);
   int best = 0;
   double best_s = -INFINITY;
-  for (int a = 0; a < A; ++a) {
-    double s = fmax(-1e9, (double)gumbel[b * A + a] + ((double)t.children_prior_logits[e0 + a] - mx) + cq[a]);
-    if (t.children_visits[e0 + a] != considered_visit) s = -INFINITY;
-    if (invalid && invalid[b * A + a]) s = -INFINITY;
-    if (s > best_s) {
-      best_s = s;
-      best = a;
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a)
+    if (a < A) {
+      double s = fmax(-1e9, (double)gumbel[b * A + a] + ((double)t.children_prior_logits[e0 + a] - mx) + cq[a]);
+      if (t.children_visits[e0 + a] != considered_visit) s = -INFINITY;
+      if (invalid && invalid[b * A + a]) s = -INFINITY;
+      if (s > best_s) {
+        best_s = s;
+        best = a;
+      }
     }
-  }
   return best;
 }
 
 // one simulation's descent: the edge (parent, action) to expand and the node index the expansion writes
 // (the existing child at the depth limit, else `next_free`)
-__global__ void search_select_kernel(SearchTree t, const float* gumbel, const uint8_t* invalid,
-                                     const int32_t* table, int max_considered, int num_simulations, int max_depth,
-                                     int next_free, int32_t* parent_out, int32_t* action_out, int32_t* node_out) {
+template <int AMAX>
+__global__ __launch_bounds__(64) void search_select_kernel(SearchTree t, const float* gumbel, const uint8_t* invalid,
+                                                           const int32_t* table, int max_considered,
+                                                           int num_simulations, int max_depth, int next_free,
+                                                           int32_t* parent_out, int32_t* action_out,
+                                                           int32_t* node_out) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= t.batch) return;
   const int A = t.num_actions;
-  double cq[kSearchMaxActions];
+  double cq[AMAX];
   // root: sequential halving over the Gumbel-top-k actions
-  search_completed_q(t, b, 0, cq);
+  search_completed_q<AMAX>(t, b, 0, cq);
   int num_valid = A, sim_index = 0;
   for (int a = 0; a < A; ++a) {
     if (invalid && invalid[b * A + a]) --num_valid;
@@ -118,32 +141,43 @@ __global__ void search_select_kernel(SearchTree t, const float* gumbel, const ui
   const int num_considered = max_considered < num_valid ? max_considered : num_valid;
   const int considered_visit = table[(int64_t)num_considered * num_simulations + sim_index];
   int node = 0;
-  int action = search_root_argmax(t, b, cq, gumbel, invalid, considered_visit);
+  int action = search_root_argmax<AMAX>(t, b, cq, gumbel, invalid, considered_visit);
   int next = t.children_index[(b * t.num_nodes + node) * A + action];
   int depth = 0;
   while (next != -1 && depth + 1 < max_depth) {
     node = next;
     ++depth;
     // interior: argmax(softmax(logits + completed Q) - N / (1 + sum N))
-    search_completed_q(t, b, node, cq);
+    search_completed_q<AMAX>(t, b, node, cq);
     const int64_t e0 = (b * t.num_nodes + node) * A;
     double mx = -INFINITY, sum_visits = 0.0;
-    for (int a = 0; a < A; ++a) {
-      cq[a] += (double)t.children_prior_logits[e0 + a];
-      mx = fmax(mx, cq[a]);
-      sum_visits += (double)t.children_visits[e0 + a];
-    }
+    double vis[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+      if (a < A) {
+        cq[a] += (double)t.children_prior_logits[e0 + a];
+        vis[a] = (double)t.children_visits[e0 + a];
+        mx = fmax(mx, cq[a]);
+        sum_visits += vis[a];
+      }
     double den = 0.0;
-    for (int a = 0; a < A; ++a) den += exp(cq[a] - mx);
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+      if (a < A) {
+        cq[a] = exp(cq[a] - mx);
+        den += cq[a];
+      }
     double best_s = -INFINITY;
     action = 0;
-    for (int a = 0; a < A; ++a) {
-      const double s = exp(cq[a] - mx) / den - (double)t.children_visits[e0 + a] / (1.0 + sum_visits);
-      if (s > best_s) {
-        best_s = s;
-        action = a;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+      if (a < A) {
+        const double s = cq[a] / den - vis[a] / (1.0 + sum_visits);
+        if (s > best_s) {
+          best_s = s;
+          action = a;
+        }
       }
-    }
     next = t.children_index[e0 + action];
   }
   parent_out[b] = node;
@@ -187,38 +221,65 @@ __global__ void search_backup_kernel(SearchTree t, const int32_t* parent_in, con
 
 // the improved policy at the root after the last simulation: action (Gumbel argmax among the most
 // visited) and action_weights = softmax(logits + completed Q)
-__global__ void search_policy_kernel(SearchTree t, const float* gumbel, const uint8_t* invalid, int32_t* action_out,
-                                     float* weights_out) {
+template <int AMAX>
+__global__ __launch_bounds__(64) void search_policy_kernel(SearchTree t, const float* gumbel, const uint8_t* invalid,
+                                                           int32_t* action_out, float* weights_out) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= t.batch) return;
   const int A = t.num_actions;
   const int64_t e0 = b * t.num_nodes * A;
-  double cq[kSearchMaxActions];
-  search_completed_q(t, b, 0, cq);
+  double cq[AMAX];
+  search_completed_q<AMAX>(t, b, 0, cq);
   int maxvisit = 0;
   for (int a = 0; a < A; ++a) maxvisit = t.children_visits[e0 + a] > maxvisit ? t.children_visits[e0 + a] : maxvisit;
-  action_out[b] = search_root_argmax(t, b, cq, gumbel, invalid, maxvisit);
+  action_out[b] = search_root_argmax<AMAX>(t, b, cq, gumbel, invalid, maxvisit);
   double mx = -INFINITY;
-  for (int a = 0; a < A; ++a) {
-    cq[a] += (double)t.children_prior_logits[e0 + a];
-    mx = fmax(mx, cq[a]);
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a)
+    if (a < A) {
+      cq[a] += (double)t.children_prior_logits[e0 + a];
+      mx = fmax(mx, cq[a]);
+    }
+  if (invalid) {
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+      if (a < A) cq[a] = invalid[b * A + a] ? -3.4028234663852886e38 : cq[a] - mx;
+    mx = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+      if (a < A) mx = fmax(mx, cq[a]);
   }
-  if (invalid)
-    for (int a = 0; a < A; ++a) cq[a] = invalid[b * A + a] ? -3.4028234663852886e38 : cq[a] - mx;
-  mx = -INFINITY;
-  for (int a = 0; a < A; ++a) mx = fmax(mx, cq[a]);
   double den = 0.0;
-  for (int a = 0; a < A; ++a) den += exp(cq[a] - mx);
-  for (int a = 0; a < A; ++a) weights_out[b * A + a] = (float)(exp(cq[a] - mx) / den);
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a)
+    if (a < A) {
+      cq[a] = exp(cq[a] - mx);
+      den += cq[a];
+    }
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a)
+    if (a < A) weights_out[b * A + a] = (float)(cq[a] / den);
 }
+
+// AMAX = the smallest of 4 / 8 / 16 / 32 that covers the action count
+#define HK_SEARCH_DISPATCH(A_, CALL)          \
+  do {                                        \
+    if ((A_) <= 4) { CALL(4); }               \
+    else if ((A_) <= 8) { CALL(8); }          \
+    else if ((A_) <= 16) { CALL(16); }        \
+    else { CALL(32); }                        \
+  } while (0)
 
 inline int launch_search_select(const SearchTree& t, const float* gumbel, const uint8_t* invalid,
                                 const int32_t* table, int max_considered, int num_simulations, int max_depth,
                                 int next_free, int32_t* parent_out, int32_t* action_out, int32_t* node_out,
                                 hipStream_t stream) {
   launch_prepare();
-  hipLaunchKernelGGL(search_select_kernel, dim3((t.batch + 255) / 256), dim3(256), 0, stream, t, gumbel, invalid,
-                     table, max_considered, num_simulations, max_depth, next_free, parent_out, action_out, node_out);
+#define HK_CALL(AM)                                                                                               \
+  hipLaunchKernelGGL(search_select_kernel<AM>, dim3((t.batch + 63) / 64), dim3(64), 0, stream, t, gumbel, invalid, \
+                     table, max_considered, num_simulations, max_depth, next_free, parent_out, action_out, node_out)
+  HK_SEARCH_DISPATCH(t.num_actions, HK_CALL);
+#undef HK_CALL
   return launch_status();
 }
 
@@ -226,7 +287,7 @@ inline int launch_search_backup(const SearchTree& t, const int32_t* parent, cons
                                 const float* prior_logits, const float* value, const float* reward,
                                 const float* discount, hipStream_t stream) {
   launch_prepare();
-  hipLaunchKernelGGL(search_backup_kernel, dim3((t.batch + 255) / 256), dim3(256), 0, stream, t, parent, action, node,
+  hipLaunchKernelGGL(search_backup_kernel, dim3((t.batch + 63) / 64), dim3(64), 0, stream, t, parent, action, node,
                      prior_logits, value, reward, discount);
   return launch_status();
 }
@@ -234,8 +295,11 @@ inline int launch_search_backup(const SearchTree& t, const int32_t* parent, cons
 inline int launch_search_policy(const SearchTree& t, const float* gumbel, const uint8_t* invalid, int32_t* action_out,
                                 float* weights_out, hipStream_t stream) {
   launch_prepare();
-  hipLaunchKernelGGL(search_policy_kernel, dim3((t.batch + 255) / 256), dim3(256), 0, stream, t, gumbel, invalid,
-                     action_out, weights_out);
+#define HK_CALL(AM)                                                                                               \
+  hipLaunchKernelGGL(search_policy_kernel<AM>, dim3((t.batch + 63) / 64), dim3(64), 0, stream, t, gumbel, invalid, \
+                     action_out, weights_out)
+  HK_SEARCH_DISPATCH(t.num_actions, HK_CALL);
+#undef HK_CALL
   return launch_status();
 }
 
