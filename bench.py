@@ -72,6 +72,20 @@ def measured_traffic(key: str):
     return None, None
 
 
+def cpu_array_baseline(games: int = 8192):
+    """The reference's own CPU formulation of the step -- broadcast [B,m,m,d] difference tensors and masks, as
+    in _jax_ops.py / _torch_ops.py -- restated in numpy (oracle/np_oracle.py), one 20-step episode of a bounded
+    sample.  (SURVEY 6 measured the reference's torch ops themselves at 0.09-0.11 M env-steps/s on 8 cores.)"""
+    from oracle import np_oracle as NO
+    fresh = NO.generate_points(games, MAX_POINTS, DIM, MAX_VALUE, 42)
+    t0 = time.perf_counter()
+    NO.rollout(fresh, EPISODE, SEED)
+    dt = time.perf_counter() - t0
+    return {"value": games * EPISODE / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"1 episode of {games} games x {EPISODE} steps ({dt:.1f} s) with oracle/np_oracle.py (numpy, the "
+                      f"reference's broadcast-tensor formulation)"}
+
+
 def capture(fn):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
@@ -400,6 +414,7 @@ def main():
             out["large_batch"] = large
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline_array_formulation"] = cpu_array_baseline()
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
