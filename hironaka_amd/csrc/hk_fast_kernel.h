@@ -322,7 +322,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
         if (e + qd < M * D) mine[e + qd] = (float)mulhi32(w[qd], (uint32_t)prm.max_value);
     }
   } else {
-    fast_load_slab<M, D, MODE == kModeStep>(lds, (const float*)prm.in, prm.in_stride, g0, ngames, lane);
+    fast_load_slab<M, D, true>(lds, (const float*)prm.in, prm.in_stride, g0, ngames, lane);
   }
   if (fetch_actions) fast_decode_actions<D>(prm, raw, c, axis_in);
   __syncthreads();
