@@ -30,7 +30,7 @@ class HironakaHipError(RuntimeError):
 
 def build(force: bool = False) -> str:
     """hipcc --offload-arch=gfx950 the kernels (cross-compiles without a GPU)."""
-    cmd = ["make", "-C", CSRC, "-s"]
+    cmd = ["make", "-C", CSRC, "-s", f"-j{min(8, os.cpu_count() or 1)}"]
     if force:
         cmd.append("-B")
     subprocess.check_call(cmd)

@@ -570,13 +570,23 @@ inline bool fast_supported(const Params& prm, int dtype) {
   return false;
 }
 
+// Each (max_points, dim) specialisation is compiled in its own translation unit (hk_fast_spec.hip, built
+// once per entry of the table by the Makefile, in parallel); the dispatcher below exists only in the main
+// unit, where the specialisations are declared but not instantiated.
+#ifndef HK_SPEC_TU
+#define HK_X(M_, D_) extern template int launch_fast_t<M_, D_>(Params, hipStream_t);
+HK_FAST_SPECS(HK_X)
+#undef HK_X
+
 inline int launch_fast(const Params& prm, hipStream_t stream) {
 #define HK_X(M_, D_) if (prm.m == M_ && prm.d == D_) return launch_fast_t<M_, D_>(prm, stream);
   HK_FAST_SPECS(HK_X)
 #undef HK_X
   return HK_ERR_UNSUPPORTED;
 }
+#endif
 
+#ifndef HK_SPEC_TU  // the per-shape translation units hold only their own specialisations
 // ---- finished-game counters: per-workgroup partials -> done_count ---------------------------------
 // block t sums count_ws[t][0..nblocks), adds it to done_count[t] (steps+1 atomics in total instead of
 // (steps+1) * nblocks on one cache line) and leaves the partials zeroed for the next launches.
@@ -659,5 +669,7 @@ inline int launch_decode(const int32_t* cls, void* mask_out, int mask_dtype, int
   hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(256), 0, stream, cls, mask_out, mask_dtype, batch, d);
   return launch_status();
 }
+
+#endif  // HK_SPEC_TU
 
 }  // namespace hk

@@ -522,6 +522,14 @@ int launch_team_d(const Params& prm, hipStream_t stream) {
   return launch_team_t<D, kModeGenerate>(prm, stream);
 }
 
+// one translation unit per dim (hk_team_spec.hip), as for the register-resident specialisations
+#ifndef HK_SPEC_TU
+extern template int launch_team_d<2>(const Params&, hipStream_t);
+extern template int launch_team_d<3>(const Params&, hipStream_t);
+extern template int launch_team_d<4>(const Params&, hipStream_t);
+extern template int launch_team_d<5>(const Params&, hipStream_t);
+extern template int launch_team_d<6>(const Params&, hipStream_t);
+
 inline int launch_team(Params& prm, hipStream_t stream) {
   const int st = plan_team(prm);
   if (st != HK_OK) return st;
@@ -534,5 +542,6 @@ inline int launch_team(Params& prm, hipStream_t stream) {
   }
   return HK_ERR_UNSUPPORTED;
 }
+#endif
 
 }  // namespace hk
