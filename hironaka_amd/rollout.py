@@ -63,26 +63,38 @@ def compute_rho(host: Union[str, Callable], agent: Union[str, Callable], *, spec
     fused = isinstance(host, str) and isinstance(agent, str)
     world_batch = batch_size if world_batch is None else world_batch
     totals = None
+    if fused:
+        # the per-loop histograms are summed on the device: partial counts accumulate in one workspace over
+        # all loops and are reduced once (the reference sums them on the host, jax_trainer.py:513,533-534)
+        workspace = None
+        for loop in range(num_of_loops):
+            pts = generate_pts(key + loop, (batch_size, m, d), max_value, dtype, False, reposition,
+                               game_offset=game_offset, device=device)
+            if workspace is None:
+                workspace = ops.rollout_workspace(batch_size, max_length - 1, spec, dtype, pts.device)
+                totals = torch.zeros(max_length, dtype=torch.int64, device=pts.device)
+            ops.rollout(pts, max_length - 1, key + loop, game_offset=game_offset, host_policy=_HOSTS[host],
+                        agent_policy=_AGENTS[agent], stages=stages, defer_counts=True, workspace=workspace)
+        if workspace is not None:
+            ops.reduce_counts(workspace, totals, batch_size, max_length - 1, spec, dtype)
+        details = details_from_done_counts(totals, batch_size * num_of_loops)
+        return rho_from_details(details), details
+    # arbitrary callables: the reference's step-by-step loop over take_actions (one fused launch per step)
+    take_action = get_take_actions("host", spec, rescale_points=False, reposition=reposition)
+    batch_decode = get_batch_decode_from_one_hot(d)
     for loop in range(num_of_loops):
         pts = generate_pts(key + loop, (batch_size, m, d), max_value, dtype, False, reposition,
                            game_offset=game_offset, device=device)
-        if fused:
-            res = ops.rollout(pts, max_length - 1, key + loop, game_offset=game_offset, host_policy=_HOSTS[host],
-                              agent_policy=_AGENTS[agent], stages=stages)
-            counts = res["done_count"]
-        else:
-            take_action = get_take_actions("host", spec, rescale_points=False, reposition=reposition)
-            batch_decode = get_batch_decode_from_one_hot(d)
-            counts = torch.zeros(max_length, dtype=torch.int64, device=pts.device)
-            counts[0] = get_dones(pts).sum()
-            flat = flatten(pts)
-            for step in range(max_length - 1):
-                host_action = host(flat, key=key * 7919 + loop * 131 + 2 * step)
-                coords = batch_decode(host_action, dtype)
-                agent_obs = make_agent_obs(flat, coords)
-                axis = torch.argmax(agent(agent_obs, key=key * 7919 + loop * 131 + 2 * step + 1), dim=-1)
-                flat = take_action(flat, coords, axis)
-                counts[step + 1] = get_dones(flat.reshape(-1, m, d)).sum()
+        counts = torch.zeros(max_length, dtype=torch.int64, device=pts.device)
+        counts[0] = get_dones(pts).sum()
+        flat = flatten(pts)
+        for step in range(max_length - 1):
+            host_action = host(flat, key=key * 7919 + loop * 131 + 2 * step)
+            coords = batch_decode(host_action, dtype)
+            agent_obs = make_agent_obs(flat, coords)
+            axis = torch.argmax(agent(agent_obs, key=key * 7919 + loop * 131 + 2 * step + 1), dim=-1)
+            flat = take_action(flat, coords, axis)
+            counts[step + 1] = get_dones(flat.reshape(-1, m, d)).sum()
         totals = counts.clone() if totals is None else totals + counts
     details = details_from_done_counts(totals, batch_size * num_of_loops)
     return rho_from_details(details), details
