@@ -355,6 +355,52 @@ def main():
                  "note": "not the headline config: shows where the kernels saturate one MI355X"}
         del fresh_l, state_l
 
+    # ---- BASELINE configs[2]: dim 4, 50 points, 262 144 games on one GPU (the team kernel: four lanes per
+    # game); a parity-test configuration, measured here so that its numbers come from the same run --------
+    config3 = None
+    if world == 1 and b == BATCH and not args.no_single_step:
+        m3, d3, b3 = 50, 4, 262144
+        fresh3 = ops.generate_points(b3, m3, d3, MAX_VALUE, seed=42)
+        cls3 = torch.randint(0, 2 ** d3 - d3 - 1, (b3,), dtype=torch.int32, device="cuda")
+        mask3 = ops.decode_host_class(cls3, d3, torch.float32)
+        axis3 = torch.randint(0, d3, (b3,), dtype=torch.int32, device="cuda")
+        out3 = torch.empty_like(fresh3)
+        state3 = torch.empty_like(fresh3)
+        dc3 = torch.zeros(EPISODE + 1, dtype=torch.int64, device="cuda")
+
+        def step3():
+            ops.step(fresh3, mask3, axis3, stages=stages, out=out3, want=("done", "reward"))
+
+        def roll3():
+            ops.rollout(state3, EPISODE, SEED, done_count=dc3, initial=fresh3, stages=stages,
+                        host_policy=A.HK_HOST_RANDOM, agent_policy=A.HK_AGENT_RANDOM)
+
+        times3 = []
+        for fn in (step3, roll3):
+            with torch.cuda.stream(side):
+                fn()
+                torch.cuda.synchronize()
+                g3 = capture(lambda: [fn() for _ in range(5)])
+            torch.cuda.synchronize()
+            g3.replay()
+            torch.cuda.synchronize()
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(4):
+                g3.replay()
+            c1.record()
+            torch.cuda.synchronize()
+            times3.append(c0.elapsed_time(c1) / 1e3 / 20)
+        bs3 = algorithmic_bytes_per_step(m3, d3)
+        config3 = {"workload": f"dim={d3}, max_points={m3}, batch={b3} (BASELINE configs[2]), hk::team_kernel<4>",
+                   "hk_step_us": times3[0] * 1e6, "hk_step_env_steps_per_s": b3 / times3[0],
+                   "hk_step_algorithmic_GBps": b3 * bs3 / times3[0] / 1e9,
+                   "hk_step_frac_of_hbm_peak": b3 * bs3 / times3[0] / 1e9 / HBM_PEAK_GBS,
+                   "fused_rollout_us_per_episode": times3[1] * 1e6,
+                   "fused_env_steps_per_s": b3 * EPISODE / times3[1],
+                   "algorithmic_bytes_per_env_step": bs3}
+        del fresh3, out3, state3
+
     if rank == 0:
         bytes_step = algorithmic_bytes_per_step(m, d)
         launches = n_full + (1 if rem else 0)
@@ -412,6 +458,8 @@ def main():
             out["boundary_step"] = api
         if large is not None:
             out["large_batch"] = large
+        if config3 is not None:
+            out["config3_dim4_50points"] = config3
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline_array_formulation"] = cpu_array_baseline()
