@@ -14,11 +14,11 @@
 //   * shift / reposition / rescale work on the registers; column minima / the game maximum are
 //     finished with two DPP quad_perm exchanges (no LDS, no ballots).
 //   * the domination test: the team mirrors its rows into the game's LDS region, then every lane
-//     tests ITS rows i against row j = 0 .. nmax-1 read from LDS (one broadcast ds_read per j for the
-//     whole team), n * n/4 row pairs per lane instead of n^2/2:
-//         t = max_k(P_j - P_i), u = min_k(P_j - P_i);   i is removed  iff  t <= 0 and (u < 0 or j < i)
-//     i.e. P_j <= P_i and (P_j != P_i or j comes first) -- _jax_ops.py:15-73 in one pass; the sign of a
-//     float difference is exact, so this is the reference's `diff >= 0` test.
+//     tests its rows i against the rows j > i read from LDS (one broadcast ds_read per j for the whole
+//     team), each unordered pair once, ~n^2/8 row pairs per lane:
+//         t = max_k(P_j - P_i), u = min_k(P_j - P_i);  j removed iff u >= 0;  i removed iff t <= 0 and u < 0
+//     -- _jax_ops.py:15-73 in one pass (ties keep the lower index); the sign of a float difference is
+//     exact, so this is the reference's `diff >= 0` test.
 //   * the bitmask of live ORIGINAL slots is kept team-uniform; removed rows become holes and the
 //     rows are squeezed again only when the widest game of the wave got narrower.
 //   * publish: pad everywhere, live rows back at their original slots, coalesced slab store.
@@ -165,18 +165,27 @@ __device__ __forceinline__ void team_rescale(float (&q)[C * D], int smax, unsign
   });
 }
 
-// The pair loop for the first CC slots of a lane, straight-line in the slots: row j of the game comes
-// from the mirror (one broadcast read for the team), every slot tests its row against it.  Slots past
-// the team's rows are +inf holes (their accumulators are never looked at).
-template <int D, int C, int CC>
-__device__ __forceinline__ void team_pairs(const float (&q)[C * D], float (&acc)[C], const float* mine, int tl,
-                                           int nmax) {
-  for (int j = 0; j < nmax; ++j) {  // wave-uniform bound; rows past a team's own count are +inf
+// The pair loop, each unordered pair ONCE.  Rows j = 4(c-1) .. 4c-1 of the game (one broadcast read per j)
+// are tested against the lane's slots 0 .. c-1, i.e. against rows i < j only (in the last slot, c-1, the
+// lanes whose row is not below j sit the test out).  One set of differences serves both directions:
+//     t = max_k(P_j - P_i), u = min_k(P_j - P_i)
+//     j is removed by i  iff  u >= 0           (P_i <= P_j; equal rows: the later one goes)
+//     i is removed by j  iff  t <= 0 and u < 0 (P_j <= P_i and not equal)
+// The verdicts on the lane's own rows i go to acc[s]; those on row j -- which another lane of the team
+// owns -- are collected as bits of jmask and OR-ed over the team afterwards.  Holes are +inf: a hole j
+// gets its bit set (harmless), a hole i never sets one (u = -inf).  The segment for c slots is
+// straight-line in the slots; segments are entered while rows remain (scalar test once per four rows).
+template <int D, int C, int CSEG>
+__device__ __forceinline__ void team_pair_segment(const float (&q)[C * D], float (&acc)[C], uint32_t (&jmask)[2],
+                                                  const float* mine, int tl, int nmax) {
+  constexpr int j0 = kTeam * (CSEG - 1);
+  const int j1 = nmax < kTeam * CSEG ? nmax : kTeam * CSEG;
+  for (int j = j0; j < j1; ++j) {
     float pj[D];
     row_load<D>(mine + j * D, pj);
-    const int jl = j - tl;  // j < 4s + tl  <=>  jl < 4s
+    bool jdead = false;
 #pragma unroll
-    for (int s = 0; s < CC; ++s) {
+    for (int s = 0; s < CSEG; ++s) {
       float t = pj[0] - q[s * D], u = t;
 #pragma unroll
       for (int k = 1; k < D; ++k) {
@@ -184,37 +193,45 @@ __device__ __forceinline__ void team_pairs(const float (&q)[C * D], float (&acc)
         t = hk_fmax(t, dk);
         u = hk_fmin(u, dk);
       }
-      // t <= 0 implies u <= 0, so "u < 0 or j < i" is the sign of u + (j < i ? -1 : 0)
-      const float e = u + ((jl < kTeam * s) ? -1.0f : 0.0f);
-      acc[s] = hk_fmin(acc[s], (e < 0.0f) ? t : 1.0f);
+      const bool below = (s < CSEG - 1) || (j0 + tl < j);  // this lane's row i = 4s + tl is below j
+      jdead |= below && (u >= 0.0f);
+      acc[s] = hk_fmin(acc[s], (below && u < 0.0f) ? t : 1.0f);
     }
+    const uint32_t bit = jdead ? (1u << (j & 31)) : 0u;
+    if (j < 32) jmask[0] |= bit;
+    else jmask[1] |= bit;
   }
 }
 
+template <int D, int C, int CSEG>
+struct TeamPairs {
+  static __device__ __forceinline__ void run(const float (&q)[C * D], float (&acc)[C], uint32_t (&jmask)[2],
+                                             const float* mine, int tl, int nmax) {
+    if (nmax <= kTeam * (CSEG - 1)) return;
+    team_pair_segment<D, C, CSEG>(q, acc, jmask, mine, tl, nmax);
+    if constexpr (CSEG < C) TeamPairs<D, C, CSEG + 1>::run(q, acc, jmask, mine, tl, nmax);
+  }
+};
+
 // _jax_ops.py:15-73.  The region must hold the mirror of the team's rows.  Removed rows become holes;
 // returns the team-uniform bitmask of the original slots that were removed.
-//     t = max_k(P_j - P_i), u = min_k(P_j - P_i);   i is removed  iff  t <= 0 and (u < 0 or j < i)
-// The loop body exists for 1, 2, 3, 4, 6, 8, 12 and 16 slots and the wave picks the smallest that
-// covers smax: no branch inside the pair loop, at most a third of the slots idle.
 template <int D, int C>
 __device__ __forceinline__ Mask64 team_newton(float (&q)[C * D], const uint32_t (&orig)[C / 4], const float* mine, int tl,
                                               int nmax, int smax) {
   float acc[C];
 #pragma unroll
   for (int s = 0; s < C; ++s) acc[s] = INFINITY;
-  if (smax <= 1) team_pairs<D, C, 1>(q, acc, mine, tl, nmax);
-  else if (smax <= 2) team_pairs<D, C, 2>(q, acc, mine, tl, nmax);
-  else if (smax <= 3) team_pairs<D, C, 3>(q, acc, mine, tl, nmax);
-  else if (smax <= 4) team_pairs<D, C, 4>(q, acc, mine, tl, nmax);
-  else if (smax <= 6) team_pairs<D, C, 6>(q, acc, mine, tl, nmax);
-  else if (smax <= 8) team_pairs<D, C, 8>(q, acc, mine, tl, nmax);
-  else if (smax <= 12) team_pairs<D, C, 12>(q, acc, mine, tl, nmax);
-  else team_pairs<D, C, 16>(q, acc, mine, tl, nmax);
+  uint32_t jmask[2] = {0u, 0u};
+  TeamPairs<D, C, 1>::run(q, acc, jmask, mine, tl, nmax);
+  jmask[0] = quad_or(jmask[0]);
+  jmask[1] = quad_or(jmask[1]);
+  const Mask64 jm = ((Mask64)jmask[1] << 32) | jmask[0];
   Mask64 dead = 0;
   unrolled_while<0, C>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
     if (s >= smax) return false;
-    const bool removed = (acc[s] <= 0.0f) && (q[s * D] < INFINITY);
+    const bool by_lower = (jm >> (kTeam * s + tl)) & 1ull;
+    const bool removed = ((acc[s] <= 0.0f) || by_lower) && (q[s * D] < INFINITY);
     dead |= removed ? ((Mask64)1 << orig_slot<s>(orig)) : (Mask64)0;
 #pragma unroll
     for (int k = 0; k < D; ++k) q[s * D + k] = removed ? INFINITY : q[s * D + k];
