@@ -4,9 +4,9 @@
 // Why not one lane per game here.  A (50, 4) game is 800 B; 64 of them fill 51 KiB of LDS, so a CU
 // holds three one-lane-per-game waves -- less than one per SIMD -- and each of them walks its rows
 // through LDS with nothing to hide the latency behind (the first version of this path did exactly that:
-// 392 us per step at 262 144 games, 13 % of the HBM roofline; this kernel: 129 us, 41 %).  Giving a game to a QUAD of lanes divides the LDS footprint and the
-// per-wave instruction stream by four (16 games, 13 KiB per wave -> ~11 waves per CU) and puts the
-// rows back in registers:
+// 392 us per step at 262 144 games, 13 % of the HBM roofline; this kernel: 111 us, 48 %).  Giving a game
+// to a QUAD of lanes divides the LDS footprint and the per-wave instruction stream by four (16 games,
+// 13 KiB per wave -> ~11 waves per CU) and puts the rows back in registers:
 //
 //   * live rows are compacted (original order kept); compact row r lives in lane r % 4 of the team,
 //     register slot r / 4 (<= 16 slots = 64 rows).  Rows [n, 4*smax) are +inf holes; smax = the
