@@ -10,9 +10,11 @@
 // Sparsity.  After a Newton-polytope pass a game of max_points = 20 typically keeps ~5 points;
 // the other rows are padding.  Each lane therefore scans its image once (live-row bitmask +
 // a check that every row is either fully available and finite or exactly the padding row),
-// GATHERS its live rows into registers q[0..n) with compile-time register indices, and every
-// later loop -- shift, reposition, the O(n^2 D) domination test, rescale -- is bounded by the
-// wave-uniform nmax = max over the 64 games of n (scalar branch out of the unrolled code).
+// GATHERS its live rows into registers q[0..n) with compile-time register indices, and a
+// transition -- shift, reposition, the O(n^2 D) domination test, rescale -- runs as branch-free
+// code for NB rows, the smallest of 1..8, 10, 12, ... that covers the wave-uniform nmax = max over
+// the 64 games of n (hk_fast_rows.h: one instruction of any kind per four cycles is all a lone wave
+// per SIMD gets, so loop control must not cost as much as the work).
 // Rows beyond a lane's own n are +inf "holes": they cannot dominate, and whatever is computed for
 // them is never published.  The image is rebuilt (pad fill + scatter of live rows to their
 // original slots, so rows keep their positions as the reference's in-place semantics requires)
@@ -23,8 +25,7 @@
 //     t = max_k(q_i - q_j),  u = min_k(q_i - q_j)          (one set of differences)
 //     row j is removed by i   iff t <= 0                    (P_i <= P_j; ties go to the lower index)
 //     row i is removed by j   iff u >= 0 and t > 0          (P_j <= P_i and not equal)
-// accumulated as ONE running minimum per row in a VGPR (no lane-mask SGPR pressure, so the same
-// code serves M = 50).  The sign of a float difference is exact, so this equals the reference's
+// accumulated as ONE running minimum per row in a VGPR (no lane-mask SGPR pressure).  The sign of a float difference is exact, so this equals the reference's
 // `diff >= 0` test (_jax_ops.py:55-56); keeping the first of equal rows equals its
 // remove_repeated (_jax_ops.py:24-40).
 //
@@ -283,8 +284,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   constexpr bool kRec = MODE == kModeRolloutRec;            // rollout + per-step observations / records
   constexpr bool kRoll = MODE == kModeRollout || kRec;
   const int lane = threadIdx.x;
-  // games per wave: 64, or fewer (lanes idle) when the batch would otherwise leave the SIMDs with
-  // fewer than two waves each -- see fast_games_per_block()
+  // games per wave: 64 (fewer only through the tuning hook of fast_games_per_block())
   const int gpb = prm.games_per_block;
   const int64_t g0 = (int64_t)blockIdx.x * gpb;
   const int64_t left = (int64_t)prm.batch - g0;
