@@ -83,13 +83,16 @@ def get_take_actions(role: str, spec: Tuple[int, int], rescale_points: bool = Fa
     stages = ops.make_stages(shift=True, reposition=reposition, newton=True, rescale=rescale_points)
 
     def take_actions(observations: torch.Tensor, actions: Optional[torch.Tensor], axis: torch.Tensor,
-                     want=()):
+                     want=(), reward_sign: float = 1.0):
+        """want (not in the reference): also return "done" / "prev_done" / "reward" / "num_points" of the
+        same launch -- {"points": [B, m*d], ...} instead of the bare points"""
         if role == "host":
             obs = observations if observations.dim() == 3 else observations.reshape(-1, m * d)
-            res = ops.step(obs, actions, axis, stages=stages, spec=None if obs.dim() == 3 else (m, d), want=want)
+            res = ops.step(obs, actions, axis, stages=stages, spec=None if obs.dim() == 3 else (m, d), want=want,
+                           reward_sign=reward_sign)
         else:
             res = ops.step(observations, None, axis, stages=stages, spec=(m, d), coords_in_record=True,
-                           want=want)
+                           want=want, reward_sign=reward_sign)
         out = res["points"].reshape(-1, m * d)
         if want:
             res["points"] = out
@@ -107,11 +110,13 @@ def get_reward_fn(role: str) -> Callable:
         def reward_fn(dones: torch.Tensor, prev_dones: torch.Tensor) -> torch.Tensor:
             return (dones & (~prev_dones)).to(torch.float32)
 
+        reward_fn.hk_reward_sign = 1.0  # lets recurrent_fn take the reward from the step launch itself
     elif role == "agent":
 
         def reward_fn(dones: torch.Tensor, prev_dones: torch.Tensor) -> torch.Tensor:
             return -(dones & (~prev_dones)).to(torch.float32)
 
+        reward_fn.hk_reward_sign = -1.0
     else:
         raise ValueError(f"role must be either host or agent. Got {role}.")
     return reward_fn

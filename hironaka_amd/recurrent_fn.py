@@ -34,7 +34,6 @@ def get_recurrent_fn_for_role(role: str, role_fn: Callable, opponent_action_fn: 
     opponent_action_fn(observations, *args, key=...) -> one-hot actions of the fixed opponent;
     reward_fn(dones, prev_dones) -> rewards."""
     m, d = spec
-    obs_preprocess, _ = get_preprocess_fns(role, spec)
     if role == "host":
         take = get_take_actions(role="host", spec=spec, rescale_points=rescale_points, reposition=reposition)
         batch_decode = get_batch_decode(d)
@@ -44,30 +43,38 @@ def get_recurrent_fn_for_role(role: str, role_fn: Callable, opponent_action_fn: 
     else:
         raise ValueError(f"role must be either 'host' or 'agent'. Got {role}.")
 
+    # the step launch itself reports done-before / done-after (and the reward when reward_fn is one of
+    # get_reward_fn's): no separate get_dones / reward kernels inside the search loop
+    sign = getattr(reward_fn, "hk_reward_sign", None)
+    want = ("done", "prev_done") + (("reward",) if sign is not None else ())
+    discounts = {}
+
+    def discount_like(observations: torch.Tensor) -> torch.Tensor:
+        key_ = (observations.shape[0], observations.device)
+        if key_ not in discounts:
+            discounts[key_] = torch.full((observations.shape[0],), discount, dtype=dtype, device=observations.device)
+        return discounts[key_]
+
     def recurrent_fn(params, key, actions: torch.Tensor, observations: torch.Tensor):
         role_fn_args, opponent_fn_args = params
-        batch_size = observations.shape[0]
-        prev_dones = get_dones(obs_preprocess(observations))
         if role == "host":
             # host acts (class ids -> masks), the agent answers, then the step happens
             coords = batch_decode(actions, dtype)
             opp = opponent_action_fn(make_agent_obs(observations, coords).to(dtype), *opponent_fn_args, key=key)
             axis = torch.argmax(opp, dim=1)
-            next_observations = take(observations, coords, axis).to(dtype)
-            points_after = next_observations
+            res = take(observations, coords, axis, want=want, reward_sign=sign or 1.0)
+            next_observations = res["points"].to(dtype)
         else:
             # the agent's axis finishes the move first; the host then answers on the new points
-            updated = take(observations, None, actions)
+            res = take(observations, None, actions, want=want, reward_sign=sign or 1.0)
+            updated = res["points"]
             opp = opponent_action_fn(updated.to(dtype), *opponent_fn_args, key=key)
             next_coords = decode_one_hot(opp, dtype)
             next_observations = make_agent_obs(updated, next_coords).to(dtype)
-            points_after = updated
-        dones = get_dones(points_after.reshape(-1, m, d))
-        rewards = reward_fn(dones, prev_dones)
+        rewards = res["reward"] if sign is not None else reward_fn(res["done"], res["prev_done"])
         policy_prior, value_prior = role_fn(next_observations, *role_fn_args, key=key)
-        out = RecurrentFnOutput(reward=rewards,
-                                discount=torch.full((batch_size,), discount, dtype=dtype, device=observations.device),
-                                prior_logits=policy_prior, value=value_prior)
+        out = RecurrentFnOutput(reward=rewards, discount=discount_like(observations), prior_logits=policy_prior,
+                                value=value_prior)
         return out, next_observations
 
     return recurrent_fn

@@ -157,10 +157,9 @@ def _run_search(params, rng_key, root: RootFnOutput, gumbel: torch.Tensor, inval
                                      max_num_considered_actions, num_simulations, max_depth, sim + 1,
                                      parent.data_ptr(), action.data_ptr(), node.data_ptr(), _stream(gumbel)),
                   "hk_search_select")
-            embedding = tree.embeddings[rows, parent.long()]
+            embedding = tree.embeddings[rows, parent]  # int32 indices are fine
             step, next_embedding = recurrent_fn(params, simulation_key(rng_key, sim), action.long(), embedding)
-            node_l = node.long()
-            tree.embeddings[rows, node_l] = next_embedding.to(tree.embeddings.dtype)
+            tree.embeddings[rows, node] = next_embedding.to(tree.embeddings.dtype)
             logits = step.prior_logits.to(torch.float32).contiguous()
             value = step.value.to(torch.float32).contiguous()
             reward = step.reward.to(torch.float32).contiguous()
