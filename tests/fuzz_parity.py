@@ -1,0 +1,99 @@
+"""Manual fuzzer (not collected by pytest): random shapes, semantics, stage masks, padding values, policies
+and batch sizes through the HIP kernels against the C oracle, for a given number of minutes on the GPU.
+
+    python tests/fuzz_parity.py --minutes 3 [--seed 0]
+
+Every mismatch prints the failing configuration and exits non-zero."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hironaka_amd import _abi as A
+from hironaka_amd import ops
+from oracle import c_oracle as CO
+
+FAST = [(4, 3), (5, 3), (10, 3), (16, 3), (20, 3), (8, 4), (20, 4)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=2.0)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    t_end = time.time() + 60 * args.minutes
+    n = 0
+    while time.time() < t_end:
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            m, d = FAST[rng.integers(0, len(FAST))]
+        else:
+            d = int(rng.integers(2, 7))
+            m = int(rng.integers(2, 65))
+        b = int(rng.choice([1, 15, 16, 17, 63, 64, 65, 200, 1000, 3000]))
+        sem = ["jax", "torch"][rng.integers(0, 2)]
+        pad = float(rng.choice([-1.0, -1.0, -1.0, -1e-8, -2.5]))
+        force = int(rng.choice([0, 0, A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC]))
+        noop, ign = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        stages = int(rng.choice([1, 2, 4, 5, 7, 7, 7, 8, 15]))
+        maxv = int(rng.choice([2, 3, 6, 20, 1000]))
+        holes = float(rng.choice([0.0, 0.3, 0.8, 0.97]))
+        p = rng.integers(0, maxv, (b, m, d)).astype(np.float32)
+        p[rng.random((b, m)) < holes] = pad
+        if rng.random() < 0.3:  # fractional (rescaled) states
+            p = np.where(p >= 0, p / np.float32(maxv), p).astype(np.float32)
+        if rng.random() < 0.2 and b > 4 and m > 2:  # irregular rows: the exact slow path
+            p[3, 1] = -3.0
+            p[2, 0, 0] = -0.5
+        cfg = dict(m=m, d=d, b=b, sem=sem, pad=pad, force=force, noop=noop, ign=ign, stages=stages, maxv=maxv,
+                   holes=holes)
+        flags_o = CO.flags_of(sem=sem, noop_if_invalid=noop, ignore_ended=ign)
+        flags_p = ops.make_flags(sem, noop, ign) | force
+        cls = rng.integers(0, 2 ** d - d - 1, b).astype(np.int64)
+        ax = rng.integers(0, d, b).astype(np.int32)
+        P = torch.as_tensor(p).cuda()
+        want = CO.step(p, cls, ax, stages=stages, flags=flags_o, padding_value=pad)
+        got = ops.step(P, torch.as_tensor(cls).cuda(), torch.as_tensor(ax).cuda(), stages=stages, flags=flags_p,
+                       padding_value=pad, want=("done", "prev_done", "reward", "num_points"))
+        for k in ("points", "done", "prev_done", "reward", "num_points"):
+            if not np.array_equal(got[k].cpu().numpy(), want[k]):
+                print("STEP MISMATCH", k, cfg)
+                sys.exit(1)
+        # fused rollout with records (JAX semantics flags only make sense with fixed policies too)
+        T = int(rng.integers(1, 25))
+        hp = int(rng.choice([A.HK_HOST_RANDOM, A.HK_HOST_RANDOM, A.HK_HOST_ALL_COORD, A.HK_HOST_ZEILLINGER]))
+        apol = int(rng.choice([A.HK_AGENT_RANDOM, A.HK_AGENT_RANDOM_LEGAL, A.HK_AGENT_CHOOSE_FIRST,
+                               A.HK_AGENT_CHOOSE_LAST]))
+        rstages = int(rng.choice([7, 7, 5, 15]))
+        seed = int(rng.integers(0, 1 << 40))
+        off = int(rng.integers(0, 1 << 33))
+        wp, wrec = CO.rollout(p, T, seed, game_offset=off, host_policy=hp, agent_policy=apol, stages=rstages,
+                              flags=flags_o, padding_value=pad, record=True)
+        Q = P.clone()
+        rec = ops.rollout(Q, T, seed, game_offset=off, host_policy=hp, agent_policy=apol, stages=rstages,
+                          flags=flags_p, padding_value=pad,
+                          record=("obs", "host_class", "axis", "done", "reward", "game_length"))
+        cfg.update(T=T, hp=hp, ap=apol, rstages=rstages, seed=seed, off=off)
+        if not np.array_equal(Q.cpu().numpy(), wp):
+            print("ROLLOUT MISMATCH points", cfg)
+            sys.exit(1)
+        for k in ("obs", "host_class", "axis", "done", "reward", "game_length"):
+            if not np.array_equal(rec[k].cpu().numpy(), wrec[k]):
+                print("ROLLOUT MISMATCH", k, cfg)
+                sys.exit(1)
+        if not np.array_equal(rec["done_count"].cpu().numpy().astype(np.uint64), wrec["done_count"]):
+            print("ROLLOUT MISMATCH done_count", cfg)
+            sys.exit(1)
+        n += 1
+        if n % 200 == 0:
+            print(f"{n} configurations ok", flush=True)
+    print(f"fuzz ok: {n} configurations", flush=True)
+
+
+if __name__ == "__main__":
+    main()
