@@ -467,7 +467,7 @@ int hk_get_features(const void* points_in, int64_t in_stride, void* features_out
   Params prm{};
   const int st = params_from_step(&s, prm);
   if (st != HK_OK) return st;
-  return launch_generic(prm, dtype, (hipStream_t)stream);
+  return launch(prm, dtype, (hipStream_t)stream);
 }
 
 int hk_decode_host_class(const int32_t* class_in, void* mask_out, int mask_dtype, int batch,

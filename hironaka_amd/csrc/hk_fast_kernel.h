@@ -479,10 +479,17 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   }
   if (kRoll && active && prm.game_length_out) prm.game_length_out[g] = length;
 
-  // ---- 5. publish: pad everywhere, live rows back in their slots ---------------------------------
+  // ---- 5. publish: pad everywhere, live rows back in their slots (or, for the observation features,
+  // at their rank in descending key order: padding rows are all equal and end up behind them) -------
   __syncthreads();
   fill_image<M, D>(mine, pad);
-  scatter_rows<M, G::C, D>(q, mine, gmask, nmax);
+  if (MODE == kModeStep && (stages & kStageFeatureSort)) {
+    int rank[G::C];
+    feature_ranks<G::C, D>(q, nmax, rank);
+    scatter_ranked<G::C, D>(q, mine, rank, nmax);
+  } else {
+    scatter_rows<M, G::C, D>(q, mine, gmask, nmax);
+  }
   __syncthreads();
   fast_store_slab<M, D>(lds, (float*)prm.out, prm.out_stride, g0, ngames, lane);
 }
@@ -561,7 +568,7 @@ inline bool fast_supported(const Params& prm, int dtype) {
   if (dtype != HK_F32) return false;
   if ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)) return false;
   if (prm.flags & (HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_TEAM)) return false;
-  if (prm.stages & kStageFeatureSort) return false;
+  if ((prm.stages & kStageFeatureSort) && prm.mode != kModeStep) return false;
   if (prm.mode == kModeZeillinger) return false;
   if (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER) return false;
 #define HK_X(M_, D_) if (prm.m == M_ && prm.d == D_) return fast_aligned_t<M_, D_>(prm);

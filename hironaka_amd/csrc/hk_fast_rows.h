@@ -349,4 +349,55 @@ __device__ __forceinline__ int run_stages(float (&q)[C * D], int nmax, const flo
   return StagesFor<C, D, 1>::run(q, nmax, c, axis, np, flags, stages);
 }
 
+// ---- observation features (jax/util.py:186-197): rows in descending order, LAST coordinate primary ------
+// a's key strictly greater than b's
+template <int D>
+__device__ __forceinline__ bool key_gt(const float* a, const float* b) {
+  bool gt = false, eq = true;
+#pragma unroll
+  for (int k = D - 1; k >= 0; --k) {
+    gt |= eq && (a[k] > b[k]);
+    eq &= (a[k] == b[k]);
+  }
+  return gt;
+}
+
+// rank[r] = position of live row r in the sorted order = number of live rows that come before it (greater
+// key; equal keys are equal rows, the lower index first).  Holes count for nothing.
+template <int C, int D>
+__device__ __forceinline__ void feature_ranks(const float (&q)[C * D], int nmax, int (&rank)[C]) {
+#pragma unroll
+  for (int r = 0; r < C; ++r) rank[r] = 0;
+  unrolled_while<0, C - 1>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    if (i + 1 >= nmax) return false;
+    const bool live_i = q[i * D] < INFINITY;
+    unrolled_while<i + 1, C>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if (j >= nmax) return false;
+      const bool live_j = q[j * D] < INFINITY;
+      const bool j_first = key_gt<D>(&q[j * D], &q[i * D]);  // otherwise i (the lower index) comes first
+      rank[j] += (!j_first && live_i) ? 1 : 0;
+      rank[i] += (j_first && live_j) ? 1 : 0;
+      return true;
+    });
+    return true;
+  });
+}
+
+// live rows to their ranks in the (pad-filled) image
+template <int C, int D>
+__device__ __forceinline__ void scatter_ranked(const float (&q)[C * D], float* mine, const int (&rank)[C], int nmax) {
+  unrolled_while<0, C>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    if (r >= nmax) return false;
+    if (q[r * D] < INFINITY) {
+      float* row = mine + rank[r] * D;
+#pragma unroll
+      for (int k = 0; k < D; ++k) row[k] = q[r * D + k];
+    }
+    return true;
+  });
+}
+
 }  // namespace hk

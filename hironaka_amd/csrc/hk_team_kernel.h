@@ -263,6 +263,48 @@ __device__ __forceinline__ void team_publish(const float (&q)[C * D], const uint
 }
 
 // register budget: three waves per SIMD up to dim 4 (<= 168 VGPRs), two beyond
+// observation features (jax/util.py:186-197): the team's live rows at their rank in descending key order
+// (last coordinate primary; equal keys are equal rows), padding behind them.  The region must hold the
+// mirror of the rows; rank = number of live rows j that come before row i.
+template <int D, int C>
+__device__ __forceinline__ void team_publish_ranked(const float (&q)[C * D], float* mine, int m, float pad, int tl,
+                                                    int nmax, int smax, bool active) {
+  int rank[C];
+#pragma unroll
+  for (int s = 0; s < C; ++s) rank[s] = 0;
+  for (int j = 0; j < nmax; ++j) {
+    float pj[D];
+    row_load<D>(mine + j * D, pj);
+    const bool live_j = pj[0] < INFINITY;
+    unrolled_while<0, C>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if (s >= smax) return false;
+      const bool j_greater = key_gt<D>(pj, &q[s * D]);
+      const bool i_greater = key_gt<D>(&q[s * D], pj);
+      const bool before = live_j && (j_greater || (!i_greater && j < kTeam * s + tl));
+      rank[s] += before ? 1 : 0;
+      return true;
+    });
+  }
+  __syncthreads();
+  float pv[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) pv[k] = pad;
+  if (active)
+    for (int i = tl; i < m; i += kTeam) row_store<D>(mine + i * D, pv);
+  unrolled_while<0, C>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (s >= smax) return false;
+    if (q[s * D] < INFINITY) {
+      float v[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) v[k] = q[s * D + k];
+      row_store<D>(mine + rank[s] * D, v);
+    }
+    return true;
+  });
+}
+
 template <int D, int MODE>
 __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Params prm) {
   extern __shared__ __align__(16) unsigned char hk_smem[];
@@ -491,7 +533,13 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
 
   // ---- 5. publish ----------------------------------------------------------------------------------
   __syncthreads();
-  team_publish<D, C>(q, orig, mine, m, pad, tl, smax, active);
+  if (MODE == kModeStep && (stages & kStageFeatureSort)) {
+    team_mirror<D, C>(q, mine, tl, smax);
+    __syncthreads();
+    team_publish_ranked<D, C>(q, mine, m, pad, tl, nmax, smax, active);
+  } else {
+    team_publish<D, C>(q, orig, mine, m, pad, tl, smax, active);
+  }
   __syncthreads();
   rows_copy_slab<false>(lds, (float*)prm.out, prm.out_stride, n_el, S, g0, ngames, lane, vec_out);
 }
@@ -502,7 +550,7 @@ inline bool team_supported(const Params& prm, int dtype) {
   if (dtype != HK_F32) return false;
   if ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)) return false;
   if (prm.flags & HK_FLAG_FORCE_GENERIC) return false;
-  if (prm.stages & kStageFeatureSort) return false;
+  if ((prm.stages & kStageFeatureSort) && prm.mode != kModeStep) return false;
   if (prm.mode == kModeZeillinger) return false;
   if (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER) return false;
   if (prm.d < 2 || prm.d > 6 || prm.m > kTeam * kTeamSlots) return false;

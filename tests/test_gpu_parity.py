@@ -571,3 +571,34 @@ def test_deferred_counts_equal_per_launch_counts(spec):
     assert torch.equal(got, want)
     with pytest.raises(ValueError):
         ops.rollout(P.clone(), T, 1, defer_counts=True)
+
+
+@pytest.mark.parametrize("spec", [(20, 3), (10, 3), (8, 4), (4, 3), (50, 4), (33, 4), (64, 3), (12, 6), (7, 3), (9, 7)])
+def test_features_match_oracle(spec):
+    """hk_get_features (jax/util.py:186-197: rescale + rows in descending order, last coordinate primary) on the
+    register-resident, team and generic kernels: game states, duplicate rows, ties on the primary coordinate,
+    all-padding games, irregular input (exact path) and record strides (agent observations)"""
+    m, d = spec
+    rng = np.random.default_rng(1000 * m + d)
+    b = 300
+    p = rand_state(rng, b, m, d, np.float32, -1.0, maxv=4, holes=0.5)   # small values: many ties and duplicates
+    p[0] = -1.0                                                          # an empty game
+    p[1, :, :] = 2.0                                                     # all rows equal
+    q = host(ops.step(dev(p), dev(rng.integers(0, 2 ** d - d - 1, b).astype(np.int32)),
+                      dev(rng.integers(0, d, b).astype(np.int32)), stages=7)["points"])
+    for states in (p, q):
+        for scale in (True, False):
+            want = CO.get_features(states, scale)
+            assert np.array_equal(host(ops.get_features(dev(states), scale)), want), (spec, scale)
+    r = p.copy()
+    if m >= 3:
+        r[5, 1] = -3.0          # irregular padding row: the wave takes the exact generic routines
+        r[6, 0, 0] = -0.5
+    assert np.array_equal(host(ops.get_features(dev(r), True)), CO.get_features(r, True))
+    # agent observation records: the subset mask trails the points and is not part of the features
+    rec = np.concatenate([q.reshape(b, m * d), rng.integers(0, 2, (b, d)).astype(np.float32)], axis=1)
+    got = host(ops.get_features(dev(rec), True, spec=spec))
+    assert np.array_equal(got, CO.get_features(q, True))
+    # big batch, ragged tail
+    big = host(ops.generate_points(5003, m, d, 20, seed=3))
+    assert np.array_equal(host(ops.get_features(dev(big), True)), CO.get_features(big, True))
