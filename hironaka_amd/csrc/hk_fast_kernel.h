@@ -238,13 +238,17 @@ __device__ inline void fast_decode_actions(const Params& prm, const RawActions<D
 
 // random / fixed policies of jax/players.py (not Zeillinger: that one runs on the generic kernel)
 // `cache` holds the Philox block of steps {2b, 2b+1}: the fused loop calls Philox every other step.
+// `zeillinger_cls`: the class Zeillinger's host picks on the current state (computed by the caller, who holds
+// the rows), used when host_policy == HK_HOST_ZEILLINGER
 template <int D>
 __device__ inline void fast_policy(uint64_t seed, int host_policy, int agent_policy, uint64_t gg, uint32_t step,
-                                   PolicyCache& cache, int& cls, int& axis, uint32_t& mask) {
+                                   PolicyCache& cache, int& cls, int& axis, uint32_t& mask,
+                                   int zeillinger_cls = 0) {
   constexpr uint32_t ncls = (1u << D) - (uint32_t)D - 1u;
   uint32_t ra, rb;
   policy_words(gg, step, seed, cache, ra, rb);
-  cls = (host_policy == HK_HOST_RANDOM) ? (int)mulhi32(ra, ncls) : (int)ncls - 1;
+  cls = (host_policy == HK_HOST_RANDOM) ? (int)mulhi32(ra, ncls)
+                                        : (host_policy == HK_HOST_ZEILLINGER ? zeillinger_cls : (int)ncls - 1);
   mask = decode_class(cls, D);
   if (agent_policy == HK_AGENT_RANDOM) {
     axis = (int)mulhi32(rb, (uint32_t)D);
@@ -267,8 +271,8 @@ __device__ inline void fast_policy(uint64_t seed, int host_policy, int agent_pol
 
 template <int D>
 __device__ inline void fast_policy(const Params& prm, uint64_t gg, uint32_t step, PolicyCache& cache,
-                                   int& cls, int& axis, uint32_t& mask) {
-  fast_policy<D>(prm.seed, prm.host_policy, prm.agent_policy, gg, step, cache, cls, axis, mask);
+                                   int& cls, int& axis, uint32_t& mask, int zeillinger_cls = 0) {
+  fast_policy<D>(prm.seed, prm.host_policy, prm.agent_policy, gg, step, cache, cls, axis, mask, zeillinger_cls);
 }
 
 // ---- the kernel: MODE is one of kModeStep / kModeRollout / kModeRolloutRec / kModeGenerate -------
@@ -358,7 +362,8 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
           __syncthreads();
         }
         uint32_t mask;
-        fast_policy<D>(prm, gg, prm.step_offset + (uint32_t)t, pcache, cls, axis, mask);
+        const int zc = (prm.host_policy == HK_HOST_ZEILLINGER && active) ? zeillinger_game<float>(mine, prm.m, prm.d) : 0;
+        fast_policy<D>(prm, gg, prm.step_offset + (uint32_t)t, pcache, cls, axis, mask, zc);
         for (int k = 0; k < prm.d; ++k) cs[k] = (float)((mask >> k) & 1u);
       } else if (MODE == kModeStep && (stages & HK_STAGE_SHIFT) && active) {
         load_coords<float>(prm, g, cs);
@@ -438,7 +443,9 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
                               g0, ngames, lane);
       }
       uint32_t mask;
-      fast_policy<D>(seed, host_policy, agent_policy, gg, step0 + (uint32_t)t, pcache, cls, axis, mask);
+      int zc = 0;
+      if (!HOT && host_policy == HK_HOST_ZEILLINGER) zc = c_zeillinger<G::C, D>(q, nmax);
+      fast_policy<D>(seed, host_policy, agent_policy, gg, step0 + (uint32_t)t, pcache, cls, axis, mask, zc);
 #pragma unroll
       for (int k = 0; k < D; ++k) c[k] = (float)((mask >> k) & 1u);
     } else if (MODE == kModeStep) {
@@ -570,7 +577,6 @@ inline bool fast_supported(const Params& prm, int dtype) {
   if (prm.flags & (HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_TEAM)) return false;
   if ((prm.stages & kStageFeatureSort) && prm.mode != kModeStep) return false;
   if (prm.mode == kModeZeillinger) return false;
-  if (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER) return false;
 #define HK_X(M_, D_) if (prm.m == M_ && prm.d == D_) return fast_aligned_t<M_, D_>(prm);
   HK_FAST_SPECS(HK_X)
 #undef HK_X

@@ -400,4 +400,60 @@ __device__ __forceinline__ void scatter_ranked(const float (&q)[C * D], float* m
   });
 }
 
+// ---- Zeillinger's host on the live rows (jax/players.py:55-109) ---------------------------------------------
+// Over the pairs of live rows: characteristic vector (L, S) = (max - min, #max + #min) of the difference
+// P_i - P_j; pairs whose difference is constant (jnp.isclose(max, min)) do not count; the first minimum of
+// (L, S) in row-major order wins -- among ordered pairs that is always an (i, j) with i < j, and the
+// compaction keeps the rows' order, so the triangle i < j in compact order finds the same pair.  The
+// subset is {argmin, argmax} of that difference; no valid pair -> class 0 (players.py:96-109).
+template <int C, int D>
+__device__ __forceinline__ int c_zeillinger(const float (&q)[C * D], int nmax) {
+  float bestL = INFINITY, bestS = INFINITY;
+  float bd[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) bd[k] = 0.0f;
+  bool have = false;
+  unrolled_while<0, C - 1>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    if (i + 1 >= nmax) return false;
+    const bool live_i = q[i * D] < INFINITY;
+    unrolled_while<i + 1, C>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if (j >= nmax) return false;
+      float v[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) v[k] = q[i * D + k] - q[j * D + k];
+      float mx = v[0], mn = v[0];
+#pragma unroll
+      for (int k = 1; k < D; ++k) {
+        mx = (v[k] > mx) ? v[k] : mx;
+        mn = (v[k] < mn) ? v[k] : mn;
+      }
+      const bool close = fabsf(mx - mn) <= 1e-8f + 1e-5f * fabsf(mn);  // jnp.isclose
+      float cnt = 0.0f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) cnt += (float)((v[k] == mx) + (v[k] == mn));
+      const float L = mx - mn;
+      const bool valid = live_i && (q[j * D] < INFINITY) && !close;
+      const bool better = valid && (L < bestL || (L == bestL && cnt < bestS));
+      bestL = better ? L : bestL;
+      bestS = better ? cnt : bestS;
+#pragma unroll
+      for (int k = 0; k < D; ++k) bd[k] = better ? v[k] : bd[k];
+      have |= better;
+      return true;
+    });
+    return true;
+  });
+  int lo = 0, hi = 0;
+  float vlo = bd[0], vhi = bd[0];
+#pragma unroll
+  for (int k = 1; k < D; ++k) {
+    if (bd[k] < vlo) { vlo = bd[k]; lo = k; }
+    if (bd[k] > vhi) { vhi = bd[k]; hi = k; }
+  }
+  if (!have || lo == hi) return 0;
+  return encode_mask((1u << lo) | (1u << hi));
+}
+
 }  // namespace hk
