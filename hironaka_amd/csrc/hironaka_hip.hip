@@ -454,6 +454,14 @@ int hk_zeillinger(const void* points, int64_t stride, int32_t* class_out, int ba
   prm.m = max_points;
   prm.d = dim;
   prm.mode = kModeZeillinger;
+  // JAX variant on a shape with a register-resident specialisation: a step launch without stages and
+  // without a state output, whose only product is class_out
+  if ((flags & HK_SEM_MASK) == HK_SEM_JAX && !(flags & (HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_TEAM))) {
+    Params fast = prm;
+    fast.mode = kModeStep;
+    fast.pad = -1.0;
+    if (fast_supported(fast, dtype)) return launch_fast(fast, (hipStream_t)stream);
+  }
   return launch_generic(prm, dtype, (hipStream_t)stream);
 }
 

@@ -346,6 +346,10 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   if (!exact) {
     // ---- slow path (whole wave): the exact generic routines on the image ------------------------
     float* cs = cbuf + lane * D;
+    if (MODE == kModeStep && prm.class_out) {  // hk_zeillinger: the class is the only output
+      if (active) prm.class_out[g] = zeillinger_game<float>(mine, prm.m, prm.d);
+      return;
+    }
     np = active ? num_points<float>(mine, M, D) : 2;
     int length = (np < 2) ? 0 : -1;
     if (kRoll && prm.count_ws) {
@@ -404,6 +408,10 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
 #pragma unroll
   for (int e = 0; e < G::C * D; ++e) q[e] = INFINITY;  // rows past nmax are holes in the straight-line bodies
   gather_rows<M, G::C, D>(q, mine, gmask, nmax);
+  if (MODE == kModeStep && prm.class_out) {  // hk_zeillinger: the class is the only output
+    if (active) prm.class_out[g] = c_zeillinger<G::C, D>(q, nmax);
+    return;
+  }
   if (!active) np = 2;  // never "done", never counted
   int length = (np < 2) ? 0 : -1;
   if (kRoll && prm.count_ws) {

@@ -602,3 +602,30 @@ def test_features_match_oracle(spec):
     # big batch, ragged tail
     big = host(ops.generate_points(5003, m, d, 20, seed=3))
     assert np.array_equal(host(ops.get_features(dev(big), True)), CO.get_features(big, True))
+
+
+@pytest.mark.parametrize("spec", [(20, 3), (10, 3), (8, 4), (20, 4), (4, 3), (7, 3), (50, 4)])
+def test_zeillinger_operator_matches_oracle(spec):
+    """hk_zeillinger (jax/players.py:55-109): on shapes with a register-resident specialisation the class comes
+    from the rows in registers, elsewhere from the generic kernel; both against the C oracle -- game states,
+    tiny values (ties in (L, S)), empty / one-point games, irregular padding (exact path)"""
+    m, d = spec
+    rng = np.random.default_rng(77 * m + d)
+    b = 500
+    p = rand_state(rng, b, m, d, np.float32, -1.0, maxv=3, holes=0.6)
+    p[0] = -1.0
+    p[1, 1:] = -1.0
+    g = host(ops.generate_points(b, m, d, 20, seed=9))
+    frac = np.where(g >= 0, g / np.float32(7.0), g).astype(np.float32)
+    for states in (p, g, frac):
+        want = CO.zeillinger(states, "jax")
+        assert np.array_equal(host(ops.zeillinger(dev(states))), want)
+        assert np.array_equal(host(ops.zeillinger(dev(states), force_generic=True)), want)
+    r = p.copy()
+    if m >= 3:
+        r[7, 1] = -3.0
+        r[8, 0, 0] = -0.5
+    assert np.array_equal(host(ops.zeillinger(dev(r))), CO.zeillinger(r, "jax"))
+    # records with a stride (agent observations) and a ragged batch
+    rec = np.concatenate([g.reshape(b, m * d), np.ones((b, d), np.float32)], axis=1)[:333]
+    assert np.array_equal(host(ops.zeillinger(dev(rec), spec=spec)), CO.zeillinger(g[:333], "jax"))
