@@ -263,6 +263,80 @@ __device__ __forceinline__ void team_publish(const float (&q)[C * D], const uint
 }
 
 // register budget: three waves per SIMD up to dim 4 (<= 168 VGPRs), two beyond
+// Zeillinger's host for a team (jax/players.py:55-109; see c_zeillinger in hk_fast_rows.h): every lane scans
+// the pairs (its rows i, rows j > i from the mirror), keeps its best (L, S, position) -- the position
+// i*64 + j makes "first minimum in row-major order" independent of the order in which the lanes visit the
+// pairs -- and two DPP exchanges leave the team's best pair, with its difference vector, in every lane.
+// The region must hold the mirror of the team's rows.
+template <int D, int C>
+__device__ __forceinline__ int team_zeillinger(const float (&q)[C * D], const float* mine, int tl, int nmax, int smax) {
+  float bestL = INFINITY, bestS = INFINITY;
+  int bestP = 0x7FFFFFFF;
+  float bd[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) bd[k] = 0.0f;
+  for (int j = 1; j < nmax; ++j) {
+    float pj[D];
+    row_load<D>(mine + j * D, pj);
+    const bool live_j = pj[0] < INFINITY;
+    unrolled_while<0, C>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if (s >= smax || kTeam * s >= j) return false;  // slots whose rows are all >= j: nothing below j left
+      const int i = kTeam * s + tl;
+      float v[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) v[k] = q[s * D + k] - pj[k];
+      float mx = v[0], mn = v[0];
+#pragma unroll
+      for (int k = 1; k < D; ++k) {
+        mx = (v[k] > mx) ? v[k] : mx;
+        mn = (v[k] < mn) ? v[k] : mn;
+      }
+      const bool close = fabsf(mx - mn) <= 1e-8f + 1e-5f * fabsf(mn);  // jnp.isclose
+      float cnt = 0.0f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) cnt += (float)((v[k] == mx) + (v[k] == mn));
+      const float L = mx - mn;
+      const int pos = i * 64 + j;
+      const bool valid = (i < j) && live_j && (q[s * D] < INFINITY) && !close;
+      const bool better = valid && (L < bestL || (L == bestL && (cnt < bestS || (cnt == bestS && pos < bestP))));
+      bestL = better ? L : bestL;
+      bestS = better ? cnt : bestS;
+      bestP = better ? pos : bestP;
+#pragma unroll
+      for (int k = 0; k < D; ++k) bd[k] = better ? v[k] : bd[k];
+      return true;
+    });
+  }
+  // the team's best: exchange with the lane 1 away, then 2 away
+#define HK_TEAM_MERGE(CTRL)                                                                              \
+  {                                                                                                      \
+    const float oL = __int_as_float(quad_perm_i<CTRL>(__float_as_int(bestL)));                           \
+    const float oS = __int_as_float(quad_perm_i<CTRL>(__float_as_int(bestS)));                           \
+    const int oP = quad_perm_i<CTRL>(bestP);                                                             \
+    const bool take = oL < bestL || (oL == bestL && (oS < bestS || (oS == bestS && oP < bestP)));        \
+    _Pragma("unroll") for (int k = 0; k < D; ++k) {                                                      \
+      const float ov = __int_as_float(quad_perm_i<CTRL>(__float_as_int(bd[k])));                         \
+      bd[k] = take ? ov : bd[k];                                                                         \
+    }                                                                                                    \
+    bestL = take ? oL : bestL;                                                                           \
+    bestS = take ? oS : bestS;                                                                           \
+    bestP = take ? oP : bestP;                                                                           \
+  }
+  HK_TEAM_MERGE(kQuadXor1)
+  HK_TEAM_MERGE(kQuadXor2)
+#undef HK_TEAM_MERGE
+  int lo = 0, hi = 0;
+  float vlo = bd[0], vhi = bd[0];
+#pragma unroll
+  for (int k = 1; k < D; ++k) {
+    if (bd[k] < vlo) { vlo = bd[k]; lo = k; }
+    if (bd[k] > vhi) { vhi = bd[k]; hi = k; }
+  }
+  if (bestP == 0x7FFFFFFF || lo == hi) return 0;
+  return encode_mask((1u << lo) | (1u << hi));
+}
+
 // observation features (jax/util.py:186-197): the team's live rows at their rank in descending key order
 // (last coordinate primary; equal keys are equal rows), padding behind them.  The region must hold the
 // mirror of the rows; rank = number of live rows j that come before row i.
@@ -401,7 +475,8 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
           __syncthreads();
         }
         uint32_t mask;
-        fast_policy<D>(prm, gg, prm.step_offset + (uint32_t)t, pcache, cls, axis, mask);
+        const int zc = (prm.host_policy == HK_HOST_ZEILLINGER && leader) ? zeillinger_game<float>(mine, m, prm.d) : 0;
+        fast_policy<D>(prm, gg, prm.step_offset + (uint32_t)t, pcache, cls, axis, mask, zc);
         if (leader)
           for (int k = 0; k < D; ++k) cs[k] = (float)((mask >> k) & 1u);
       } else if (MODE == kModeStep && (stages & HK_STAGE_SHIFT) && leader) {
@@ -467,7 +542,14 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
         __syncthreads();
       }
       uint32_t mask;
-      fast_policy<D>(prm, gg, prm.step_offset + (uint32_t)t, pcache, cls, axis, mask);
+      int zc = 0;
+      if (prm.host_policy == HK_HOST_ZEILLINGER) {
+        __syncthreads();
+        team_mirror<D, C>(q, mine, tl, smax);
+        __syncthreads();
+        zc = team_zeillinger<D, C>(q, mine, tl, nmax, smax);
+      }
+      fast_policy<D>(prm, gg, prm.step_offset + (uint32_t)t, pcache, cls, axis, mask, zc);
 #pragma unroll
       for (int k = 0; k < D; ++k) c[k] = (float)((mask >> k) & 1u);
     } else if (MODE == kModeStep) {
@@ -552,7 +634,6 @@ inline bool team_supported(const Params& prm, int dtype) {
   if (prm.flags & HK_FLAG_FORCE_GENERIC) return false;
   if ((prm.stages & kStageFeatureSort) && prm.mode != kModeStep) return false;
   if (prm.mode == kModeZeillinger) return false;
-  if (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER) return false;
   if (prm.d < 2 || prm.d > 6 || prm.m > kTeam * kTeamSlots) return false;
   return true;
 }
