@@ -454,13 +454,17 @@ int hk_zeillinger(const void* points, int64_t stride, int32_t* class_out, int ba
   prm.m = max_points;
   prm.d = dim;
   prm.mode = kModeZeillinger;
-  // JAX variant on a shape with a register-resident specialisation: a step launch without stages and
-  // without a state output, whose only product is class_out
-  if ((flags & HK_SEM_MASK) == HK_SEM_JAX && !(flags & (HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_TEAM))) {
+  // JAX variant on the register-resident / team kernels: a step launch without stages and without a state
+  // output, whose only product is class_out
+  if ((flags & HK_SEM_MASK) == HK_SEM_JAX && !(flags & HK_FLAG_FORCE_GENERIC)) {
     Params fast = prm;
     fast.mode = kModeStep;
     fast.pad = -1.0;
     if (fast_supported(fast, dtype)) return launch_fast(fast, (hipStream_t)stream);
+    if (team_supported(fast, dtype)) {
+      const int ts = launch_team(fast, (hipStream_t)stream);
+      if (ts != HK_ERR_UNSUPPORTED) return ts;
+    }
   }
   return launch_generic(prm, dtype, (hipStream_t)stream);
 }

@@ -459,6 +459,10 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
   if (!exact) {
     // ---- slow path (whole wave): the exact generic routines on the image, one lane per game ------
     float* cs = cbuf + tg * D;
+    if (MODE == kModeStep && prm.class_out) {  // hk_zeillinger: the class is the only output
+      if (leader) prm.class_out[g] = zeillinger_game<float>(mine, m, prm.d);
+      return;
+    }
     np = leader ? num_points<float>(mine, m, D) : 2;
     int length = (np < 2) ? 0 : -1;
     if (MODE == kModeRollout && prm.count_ws) {
@@ -523,6 +527,14 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
     np = 2;  // never "done", never counted
   }
   team_gather<D, C>(q, orig, mine, gmask, tl, smax, false);
+  if (MODE == kModeStep && prm.class_out) {  // hk_zeillinger: the class is the only output
+    __syncthreads();
+    team_mirror<D, C>(q, mine, tl, smax);
+    __syncthreads();
+    const int zc = team_zeillinger<D, C>(q, mine, tl, nmax, smax);
+    if (leader) prm.class_out[g] = zc;
+    return;
+  }
   int length = (np < 2) ? 0 : -1;
   if (MODE == kModeRollout && prm.count_ws) {
     const unsigned long long b0 = __ballot(leader && np < 2);

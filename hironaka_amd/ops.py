@@ -237,7 +237,8 @@ def decode_host_class(cls: torch.Tensor, dim: int, dtype=torch.float32) -> torch
     return out.reshape(*cls.shape, dim)
 
 
-def zeillinger(points: torch.Tensor, sem: str = "jax", spec=None, force_generic: bool = False) -> torch.Tensor:
+def zeillinger(points: torch.Tensor, sem: str = "jax", spec=None, force_generic: bool = False,
+               force_team: bool = False) -> torch.Tensor:
     """Zeillinger host: class id per game.  sem="jax": jax/players.py:84-109 (degenerate -> 0);
     sem="list": host.py:70-95 on padded rows (-1 for a game with fewer than 2 points).
     points: [B, m, d], or [B, stride] records with spec=(m, d) (e.g. agent observations)."""
@@ -253,7 +254,8 @@ def zeillinger(points: torch.Tensor, sem: str = "jax", spec=None, force_generic:
     else:
         raise ValueError("points must be [B, m, d], or [B, stride] together with spec=(m, d)")
     out = torch.empty(b, dtype=torch.int32, device=pts.device)
-    flags = A.SEMANTICS[sem] | (A.HK_FLAG_FORCE_GENERIC if force_generic else 0)
+    flags = (A.SEMANTICS[sem] | (A.HK_FLAG_FORCE_GENERIC if force_generic else 0)
+             | (A.HK_FLAG_FORCE_TEAM if force_team else 0))
     with torch.cuda.device(pts.device):
         check(lib().hk_zeillinger(pts.data_ptr(), stride, out.data_ptr(), b, m, d, _TORCH2HK[pts.dtype],
                                   flags, _stream(pts)), "hk_zeillinger")

@@ -604,7 +604,7 @@ def test_features_match_oracle(spec):
     assert np.array_equal(host(ops.get_features(dev(big), True)), CO.get_features(big, True))
 
 
-@pytest.mark.parametrize("spec", [(20, 3), (10, 3), (8, 4), (20, 4), (4, 3), (7, 3), (50, 4)])
+@pytest.mark.parametrize("spec", [(20, 3), (10, 3), (8, 4), (20, 4), (4, 3), (7, 3), (50, 4), (64, 6), (9, 7)])
 def test_zeillinger_operator_matches_oracle(spec):
     """hk_zeillinger (jax/players.py:55-109): on shapes with a register-resident specialisation the class comes
     from the rows in registers, elsewhere from the generic kernel; both against the C oracle -- game states,
@@ -621,6 +621,8 @@ def test_zeillinger_operator_matches_oracle(spec):
         want = CO.zeillinger(states, "jax")
         assert np.array_equal(host(ops.zeillinger(dev(states))), want)
         assert np.array_equal(host(ops.zeillinger(dev(states), force_generic=True)), want)
+        if d <= 6 and m <= 64:
+            assert np.array_equal(host(ops.zeillinger(dev(states), force_team=True)), want)
     r = p.copy()
     if m >= 3:
         r[7, 1] = -3.0
