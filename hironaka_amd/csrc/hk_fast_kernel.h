@@ -79,31 +79,35 @@ __device__ inline int wave_max(int v, int hi) {
 // dependent instruction: Q wide loads per lane in flight together (one HBM round trip per launch, not
 // one per request).  Chunks past a partial slab re-read its last chunk (always a valid address) and
 // are simply not written to the image.
-template <int M, int D, bool ALL_IN_FLIGHT = true>
-__device__ inline void fast_load_slab(float* lds, const float* in, int64_t in_stride, int64_t g0,
-                                      int ngames, int lane) {
+// element offsets of chunk q (W floats) of a slab: in HBM (from the slab's first record) and in the LDS
+// image.  Contiguous records (stride == M*D, the usual case) and an unpadded image need no division.
+template <int M, int D, bool CONTIG>
+__device__ __forceinline__ int64_t slab_chunk_global(int q, int64_t stride) {
+  using G = FastGeom<M, D>;
+  if (CONTIG) return (int64_t)q * G::W;
+  const int g = q / G::Q, c = q - g * G::Q;
+  return g * stride + c * G::W;
+}
+template <int M, int D>
+__device__ __forceinline__ int slab_chunk_lds(int q) {
+  using G = FastGeom<M, D>;
+  if (G::S == G::N) return q * G::W;
+  const int g = q / G::Q, c = q - g * G::Q;
+  return g * G::S + c * G::W;
+}
+
+template <int M, int D, bool CONTIG>
+__device__ __forceinline__ void fast_load_slab_impl(float* lds, const float* base, int64_t in_stride, int ngames,
+                                                    int lane) {
   using G = FastGeom<M, D>;
   using V = typename VecOf<G::W>::type;
   const int total = ngames * G::Q;
-  if (!ALL_IN_FLIGHT) {
-#pragma unroll
-    for (int it = 0; it < G::Q; ++it) {
-      const int q = lane + it * kWave;
-      if (q < total) {
-        const int g = q / G::Q, c = q - g * G::Q;
-        const V v = *reinterpret_cast<const V*>(in + (g0 + g) * in_stride + c * G::W);
-        *reinterpret_cast<V*>(lds + g * G::S + c * G::W) = v;
-      }
-    }
-    return;
-  }
   V v[G::Q];
 #pragma unroll
   for (int it = 0; it < G::Q; ++it) {
     int q = lane + it * kWave;
     q = q < total ? q : total - 1;
-    const int g = q / G::Q, c = q - g * G::Q;
-    v[it] = *reinterpret_cast<const V*>(in + (g0 + g) * in_stride + c * G::W);
+    v[it] = *reinterpret_cast<const V*>(base + slab_chunk_global<M, D, CONTIG>(q, in_stride));
   }
   // an opaque use of every chunk right here: otherwise the compiler sinks each load into the
   // conditional block of its store and waits for it there, one round trip per chunk
@@ -112,16 +116,23 @@ __device__ inline void fast_load_slab(float* lds, const float* in, int64_t in_st
 #pragma unroll
   for (int it = 0; it < G::Q; ++it) {
     const int q = lane + it * kWave;
-    const int g = q / G::Q, c = q - g * G::Q;
-    if (q < total) *reinterpret_cast<V*>(lds + g * G::S + c * G::W) = v[it];
+    if (q < total) *reinterpret_cast<V*>(lds + slab_chunk_lds<M, D>(q)) = v[it];
   }
+}
+
+template <int M, int D>
+__device__ inline void fast_load_slab(float* lds, const float* in, int64_t in_stride, int64_t g0,
+                                      int ngames, int lane) {
+  const float* base = in + g0 * in_stride;
+  if (in_stride == FastGeom<M, D>::N) fast_load_slab_impl<M, D, true>(lds, base, in_stride, ngames, lane);
+  else fast_load_slab_impl<M, D, false>(lds, base, in_stride, ngames, lane);
 }
 
 // Stores need no such care (nothing waits for them); the image is read a few chunks at a time so that a
 // store inside the rollout loop (per-step observations) adds little to the loop's register pressure.
-template <int M, int D>
-__device__ inline void fast_store_slab(const float* lds, float* out, int64_t out_stride, int64_t g0,
-                                       int ngames, int lane) {
+template <int M, int D, bool CONTIG>
+__device__ __forceinline__ void fast_store_slab_impl(const float* lds, float* base, int64_t out_stride, int ngames,
+                                                     int lane) {
   using G = FastGeom<M, D>;
   using V = typename VecOf<G::W>::type;
   constexpr int kBatch = 4;
@@ -132,18 +143,25 @@ __device__ inline void fast_store_slab(const float* lds, float* out, int64_t out
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {  // the image holds kWave games whatever ngames is
       const int q = lane + (i0 + u < G::Q ? i0 + u : G::Q - 1) * kWave;
-      const int g = q / G::Q, c = q - g * G::Q;
-      v[u] = *reinterpret_cast<const V*>(lds + g * G::S + c * G::W);
+      v[u] = *reinterpret_cast<const V*>(lds + slab_chunk_lds<M, D>(q));
     }
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) asm volatile("" : "+v"(v[u]));
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
       const int q = lane + (i0 + u) * kWave;
-      const int g = q / G::Q, c = q - g * G::Q;
-      if (i0 + u < G::Q && q < total) *reinterpret_cast<V*>(out + (g0 + g) * out_stride + c * G::W) = v[u];
+      if (i0 + u < G::Q && q < total)
+        *reinterpret_cast<V*>(base + slab_chunk_global<M, D, CONTIG>(q, out_stride)) = v[u];
     }
   }
+}
+
+template <int M, int D>
+__device__ inline void fast_store_slab(const float* lds, float* out, int64_t out_stride, int64_t g0,
+                                       int ngames, int lane) {
+  float* base = out + g0 * out_stride;
+  if (out_stride == FastGeom<M, D>::N) fast_store_slab_impl<M, D, true>(lds, base, out_stride, ngames, lane);
+  else fast_store_slab_impl<M, D, false>(lds, base, out_stride, ngames, lane);
 }
 
 // ---- image <-> registers --------------------------------------------------------------------------
@@ -162,15 +180,20 @@ __device__ inline void scan_image(const float* mine, float fill, MaskT<M>& live,
   }
   live = 0;
   ok = true;
+  const uint32_t fill_bits = __float_as_uint(fill);
 #pragma unroll
   for (int i = 0; i < M; ++i) {
-    bool ge = true, fl = true;
+    // on the bit patterns: a row is available iff its largest pattern is below +inf's ([+0, +inf): no
+    // negative, -0, inf or NaN), and it is the padding row iff smallest == largest == the fill value's
+    uint32_t hi = __float_as_uint(p[i * D]), lo = hi;
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
-      // [+0, +inf) as an unsigned compare on the bit pattern (excludes negatives, -0, inf, NaN)
-      ge &= (__float_as_uint(p[i * D + k]) < 0x7F800000u);
-      fl &= (p[i * D + k] == fill);
+    for (int k = 1; k < D; ++k) {
+      const uint32_t u = __float_as_uint(p[i * D + k]);
+      hi = u > hi ? u : hi;
+      lo = u < lo ? u : lo;
     }
+    const bool ge = hi < 0x7F800000u;
+    const bool fl = (lo == fill_bits) && (hi == fill_bits);
     ok &= (ge | fl);
     live |= ge ? ((MaskT<M>)1 << i) : (MaskT<M>)0;
   }
@@ -326,7 +349,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
         if (e + qd < M * D) mine[e + qd] = (float)mulhi32(w[qd], (uint32_t)prm.max_value);
     }
   } else {
-    fast_load_slab<M, D, true>(lds, (const float*)prm.in, prm.in_stride, g0, ngames, lane);
+    fast_load_slab<M, D>(lds, (const float*)prm.in, prm.in_stride, g0, ngames, lane);
   }
   if (fetch_actions) fast_decode_actions<D>(prm, raw, c, axis_in);
   __syncthreads();
