@@ -96,36 +96,49 @@ __device__ __forceinline__ int slab_chunk_lds(int q) {
   return g * G::S + c * G::W;
 }
 
+// the slab's requests (issue) and their way into the image (commit) are separate calls so that a kernel can
+// put other loads between them
+template <int M, int D>
+struct SlabRegs {
+  typename VecOf<FastGeom<M, D>::W>::type v[FastGeom<M, D>::Q];
+};
+
 template <int M, int D, bool CONTIG>
-__device__ __forceinline__ void fast_load_slab_impl(float* lds, const float* base, int64_t in_stride, int ngames,
-                                                    int lane) {
+__device__ __forceinline__ void fast_slab_issue_impl(SlabRegs<M, D>& r, const float* base, int64_t in_stride,
+                                                     int ngames, int lane) {
   using G = FastGeom<M, D>;
   using V = typename VecOf<G::W>::type;
   const int total = ngames * G::Q;
-  V v[G::Q];
 #pragma unroll
   for (int it = 0; it < G::Q; ++it) {
     int q = lane + it * kWave;
     q = q < total ? q : total - 1;
-    v[it] = *reinterpret_cast<const V*>(base + slab_chunk_global<M, D, CONTIG>(q, in_stride));
-  }
-  // an opaque use of every chunk right here: otherwise the compiler sinks each load into the
-  // conditional block of its store and waits for it there, one round trip per chunk
-#pragma unroll
-  for (int it = 0; it < G::Q; ++it) asm volatile("" : "+v"(v[it]));
-#pragma unroll
-  for (int it = 0; it < G::Q; ++it) {
-    const int q = lane + it * kWave;
-    if (q < total) *reinterpret_cast<V*>(lds + slab_chunk_lds<M, D>(q)) = v[it];
+    r.v[it] = *reinterpret_cast<const V*>(base + slab_chunk_global<M, D, CONTIG>(q, in_stride));
   }
 }
 
 template <int M, int D>
-__device__ inline void fast_load_slab(float* lds, const float* in, int64_t in_stride, int64_t g0,
-                                      int ngames, int lane) {
+__device__ __forceinline__ void fast_slab_issue(SlabRegs<M, D>& r, const float* in, int64_t in_stride, int64_t g0,
+                                                int ngames, int lane) {
   const float* base = in + g0 * in_stride;
-  if (in_stride == FastGeom<M, D>::N) fast_load_slab_impl<M, D, true>(lds, base, in_stride, ngames, lane);
-  else fast_load_slab_impl<M, D, false>(lds, base, in_stride, ngames, lane);
+  if (in_stride == FastGeom<M, D>::N) fast_slab_issue_impl<M, D, true>(r, base, in_stride, ngames, lane);
+  else fast_slab_issue_impl<M, D, false>(r, base, in_stride, ngames, lane);
+}
+
+template <int M, int D>
+__device__ __forceinline__ void fast_slab_commit(SlabRegs<M, D>& r, float* lds, int ngames, int lane) {
+  using G = FastGeom<M, D>;
+  using V = typename VecOf<G::W>::type;
+  const int total = ngames * G::Q;
+  // an opaque use of every chunk right here: otherwise the compiler sinks each load into the
+  // conditional block of its store and waits for it there, one round trip per chunk
+#pragma unroll
+  for (int it = 0; it < G::Q; ++it) asm volatile("" : "+v"(r.v[it]));
+#pragma unroll
+  for (int it = 0; it < G::Q; ++it) {
+    const int q = lane + it * kWave;
+    if (q < total) *reinterpret_cast<V*>(lds + slab_chunk_lds<M, D>(q)) = r.v[it];
+  }
 }
 
 // Stores need no such care (nothing waits for them); the image is read a few chunks at a time so that a
@@ -304,7 +317,10 @@ __device__ inline void fast_policy(const Params& prm, uint64_t gg, uint32_t step
 // wave per SIMD pays a fetch bubble for every taken branch, and the per-step tests of stages / flags /
 // policies are ~15 % of a fused rollout (measured: 43.5 -> 38.1 us per 20-step episode of 65 536 games).
 template <int M, int D, int MODE, bool HOT = false>
-__global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1 : 2)) void fast_kernel(const Params prm) {
+__global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1 : 2)) void fast_kernel(const float* in0, int64_t in_stride0, int batch0, int gpb0, const Params prm) {
+  // in0 / in_stride0 / batch0 / gpb0 repeat prm.in / in_stride / batch / games_per_block as leading scalar
+  // arguments: those are PRELOADED into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count), so the
+  // slab's loads can be issued without waiting for the first scalar load of the argument block
   using G = FastGeom<M, D>;
   __shared__ __align__(16) float lds[kWave * G::S];
   __shared__ float cbuf[kWave * D];  // slow path only: subset mask / row scratch per lane
@@ -312,12 +328,14 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   constexpr bool kRoll = MODE == kModeRollout || kRec;
   const int lane = threadIdx.x;
   // games per wave: 64 (fewer only through the tuning hook of fast_games_per_block())
-  const int gpb = prm.games_per_block;
+  const int gpb = gpb0;
   const int64_t g0 = (int64_t)blockIdx.x * gpb;
-  const int64_t left = (int64_t)prm.batch - g0;
+  const int64_t left = (int64_t)batch0 - g0;
   const int ngames = (int)(left < gpb ? left : gpb);
   const bool active = lane < ngames;
   const int64_t g = g0 + lane;
+  SlabRegs<M, D> slab;
+  if (MODE != kModeGenerate) fast_slab_issue<M, D>(slab, in0, in_stride0, g0, ngames, lane);
   const uint64_t gg = prm.game_offset + (uint64_t)g;
   float* mine = lds + lane * G::S;
   const float pad = (float)prm.pad;
@@ -328,7 +346,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   const int nsteps = (kRoll) ? prm.steps : 1;
   PolicyCache pcache;
 
-  // step mode: issue the action loads first so their latency hides under the slab copy
+  // step mode: the action loads join the slab's requests in flight
   float c[D];
   int axis_in = -1;
 #pragma unroll
@@ -349,7 +367,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
         if (e + qd < M * D) mine[e + qd] = (float)mulhi32(w[qd], (uint32_t)prm.max_value);
     }
   } else {
-    fast_load_slab<M, D>(lds, (const float*)prm.in, prm.in_stride, g0, ngames, lane);
+    fast_slab_commit<M, D>(slab, lds, ngames, lane);
   }
   if (fetch_actions) fast_decode_actions<D>(prm, raw, c, axis_in);
   __syncthreads();
@@ -588,16 +606,21 @@ int launch_fast_t(Params prm, hipStream_t stream) {
   const unsigned grid = (unsigned)(((int64_t)prm.batch + prm.games_per_block - 1) / prm.games_per_block);
   launch_prepare();
   if (prm.mode == kModeStep)
-    hipLaunchKernelGGL((fast_kernel<M, D, kModeStep>), dim3(grid), dim3(kWave), 0, stream, prm);
+    hipLaunchKernelGGL((fast_kernel<M, D, kModeStep>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
+                       prm.in_stride, prm.batch, prm.games_per_block, prm);
   else if (prm.mode == kModeRollout && (prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out ||
                                         prm.r_reward_out))
-    hipLaunchKernelGGL((fast_kernel<M, D, kModeRolloutRec>), dim3(grid), dim3(kWave), 0, stream, prm);
+    hipLaunchKernelGGL((fast_kernel<M, D, kModeRolloutRec>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
+                       prm.in_stride, prm.batch, prm.games_per_block, prm);
   else if (prm.mode == kModeRollout && fast_hot_config(prm))
-    hipLaunchKernelGGL((fast_kernel<M, D, kModeRollout, true>), dim3(grid), dim3(kWave), 0, stream, prm);
+    hipLaunchKernelGGL((fast_kernel<M, D, kModeRollout, true>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
+                       prm.in_stride, prm.batch, prm.games_per_block, prm);
   else if (prm.mode == kModeRollout)
-    hipLaunchKernelGGL((fast_kernel<M, D, kModeRollout>), dim3(grid), dim3(kWave), 0, stream, prm);
+    hipLaunchKernelGGL((fast_kernel<M, D, kModeRollout>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
+                       prm.in_stride, prm.batch, prm.games_per_block, prm);
   else
-    hipLaunchKernelGGL((fast_kernel<M, D, kModeGenerate>), dim3(grid), dim3(kWave), 0, stream, prm);
+    hipLaunchKernelGGL((fast_kernel<M, D, kModeGenerate>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
+                       prm.in_stride, prm.batch, prm.games_per_block, prm);
   return launch_status();
 }
 
