@@ -143,12 +143,11 @@ __device__ __forceinline__ void fast_slab_commit(SlabRegs<M, D>& r, float* lds, 
 
 // Stores need no such care (nothing waits for them); the image is read a few chunks at a time so that a
 // store inside the rollout loop (per-step observations) adds little to the loop's register pressure.
-template <int M, int D, bool CONTIG>
+template <int M, int D, bool CONTIG, int kBatch>
 __device__ __forceinline__ void fast_store_slab_impl(const float* lds, float* base, int64_t out_stride, int ngames,
                                                      int lane) {
   using G = FastGeom<M, D>;
   using V = typename VecOf<G::W>::type;
-  constexpr int kBatch = 4;
   const int total = ngames * G::Q;
 #pragma unroll
   for (int i0 = 0; i0 < G::Q; i0 += kBatch) {
@@ -169,12 +168,14 @@ __device__ __forceinline__ void fast_store_slab_impl(const float* lds, float* ba
   }
 }
 
-template <int M, int D>
+// kBatch: image chunks read per round (4 inside the rollout loop; everything at once for the final store,
+// when the registers are free and the LDS latency would otherwise be paid once per round)
+template <int M, int D, int kBatch = 4>
 __device__ inline void fast_store_slab(const float* lds, float* out, int64_t out_stride, int64_t g0,
                                        int ngames, int lane) {
   float* base = out + g0 * out_stride;
-  if (out_stride == FastGeom<M, D>::N) fast_store_slab_impl<M, D, true>(lds, base, out_stride, ngames, lane);
-  else fast_store_slab_impl<M, D, false>(lds, base, out_stride, ngames, lane);
+  if (out_stride == FastGeom<M, D>::N) fast_store_slab_impl<M, D, true, kBatch>(lds, base, out_stride, ngames, lane);
+  else fast_store_slab_impl<M, D, false, kBatch>(lds, base, out_stride, ngames, lane);
 }
 
 // ---- image <-> registers --------------------------------------------------------------------------
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
     scatter_rows<M, G::C, D>(q, mine, gmask, nmax);
   }
   __syncthreads();
-  fast_store_slab<M, D>(lds, (float*)prm.out, prm.out_stride, g0, ngames, lane);
+  fast_store_slab<M, D, G::Q>(lds, (float*)prm.out, prm.out_stride, g0, ngames, lane);
 }
 
 // ---- the specialisation table ------------------------------------------------------------------
