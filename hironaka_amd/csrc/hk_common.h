@@ -20,6 +20,10 @@ enum Mode : int { kModeStep = 0, kModeRollout = 1, kModeGenerate = 2, kModeZeill
 // template-only variant of kModeRollout: the rollout that also writes per-step observations / records
 // (kept out of the plain rollout kernel, whose loop it would cost ~40 VGPRs)
 constexpr int kModeRolloutRec = 4;
+// template-only variant of kModeStep: the step launches whose product is not the next state -- the sorted
+// observation features (hk_get_features) and Zeillinger's class (hk_zeillinger) -- kept out of the plain step
+// kernel, which then carries neither their code nor their registers
+constexpr int kModeStepAux = 5;
 
 // RNG stream ids (DESIGN.md "Randomness"); the oracle uses the same two numbers.
 constexpr uint32_t kStreamPolicy = 0u;

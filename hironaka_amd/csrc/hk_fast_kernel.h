@@ -327,6 +327,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   __shared__ float cbuf[kWave * D];  // slow path only: subset mask / row scratch per lane
   constexpr bool kRec = MODE == kModeRolloutRec;            // rollout + per-step observations / records
   constexpr bool kRoll = MODE == kModeRollout || kRec;
+  constexpr bool kStep = MODE == kModeStep || MODE == kModeStepAux;  // Aux: features / Zeillinger's class
   const int lane = threadIdx.x;
   // games per wave: 64 (fewer only through the tuning hook of fast_games_per_block())
   const int gpb = gpb0;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
 #pragma unroll
   for (int k = 0; k < D; ++k) c[k] = 0.0f;
   RawActions<D> raw;
-  const bool fetch_actions = MODE == kModeStep && (stages & HK_STAGE_SHIFT) && active;
+  const bool fetch_actions = kStep && (stages & HK_STAGE_SHIFT) && active;
   if (fetch_actions) fast_fetch_actions<D>(prm, g, M, raw);
 
   // ---- 1. the image --------------------------------------------------------------------------------
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   if (!exact) {
     // ---- slow path (whole wave): the exact generic routines on the image ------------------------
     float* cs = cbuf + lane * D;
-    if (MODE == kModeStep && prm.class_out) {  // hk_zeillinger: the class is the only output
+    if (MODE == kModeStepAux && prm.class_out) {  // hk_zeillinger: the class is the only output
       if (active) prm.class_out[g] = zeillinger_game<float>(mine, prm.m, prm.d);
       return;
     }
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
         const int zc = (prm.host_policy == HK_HOST_ZEILLINGER && active) ? zeillinger_game<float>(mine, prm.m, prm.d) : 0;
         fast_policy<D>(prm, gg, prm.step_offset + (uint32_t)t, pcache, cls, axis, mask, zc);
         for (int k = 0; k < prm.d; ++k) cs[k] = (float)((mask >> k) & 1u);
-      } else if (MODE == kModeStep && (stages & HK_STAGE_SHIFT) && active) {
+      } else if (kStep && (stages & HK_STAGE_SHIFT) && active) {
         load_coords<float>(prm, g, cs);
         axis = axis_in;
       }
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
           const unsigned long long bd = __ballot(active && done);
           if (lane == 0) count_add(prm.count_ws + (size_t)(t + 1) * gridDim.x + blockIdx.x, (uint32_t)__popcll(bd));
         }
-      } else if (MODE == kModeStep && active) {
+      } else if (kStep && active) {
         if (prm.done_out) prm.done_out[g] = done;
         if (prm.prev_done_out) prm.prev_done_out[g] = prev_done;
         if (prm.reward_out) prm.reward_out[g] = prm.reward_sign * (float)(done && !prev_done);
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
 #pragma unroll
   for (int e = 0; e < G::C * D; ++e) q[e] = INFINITY;  // rows past nmax are holes in the straight-line bodies
   gather_rows<M, G::C, D>(q, mine, gmask, nmax);
-  if (MODE == kModeStep && prm.class_out) {  // hk_zeillinger: the class is the only output
+  if (MODE == kModeStepAux && prm.class_out) {  // hk_zeillinger: the class is the only output
     if (active) prm.class_out[g] = c_zeillinger<G::C, D>(q, nmax);
     return;
   }
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
       fast_policy<D>(seed, host_policy, agent_policy, gg, step0 + (uint32_t)t, pcache, cls, axis, mask, zc);
 #pragma unroll
       for (int k = 0; k < D; ++k) c[k] = (float)((mask >> k) & 1u);
-    } else if (MODE == kModeStep) {
+    } else if (kStep) {
       axis = axis_in;  // c[] and the axis were fetched at kernel entry
     }
     const bool prev_done = np < 2;
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
         nmax = wave_max(active ? np : 0, nmax - 1);
         gather_rows<M, G::C, D>(q, mine, gmask, nprev);  // rows [nmax, nprev) become holes again
       }
-    } else if (MODE == kModeStep && active) {
+    } else if (kStep && active) {
       if (prm.done_out) prm.done_out[g] = done;
       if (prm.prev_done_out) prm.prev_done_out[g] = prev_done;
       if (prm.reward_out) prm.reward_out[g] = prm.reward_sign * (float)(done && !prev_done);
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   // at their rank in descending key order: padding rows are all equal and end up behind them) -------
   __syncthreads();
   fill_image<M, D>(mine, pad);
-  if (MODE == kModeStep && (stages & kStageFeatureSort)) {
+  if (MODE == kModeStepAux && (stages & kStageFeatureSort)) {
     int rank[G::C];
     feature_ranks<G::C, D>(q, nmax, rank);
     scatter_ranked<G::C, D>(q, mine, rank, nmax);
@@ -606,7 +607,10 @@ int launch_fast_t(Params prm, hipStream_t stream) {
   prm.games_per_block = fast_games_per_block(prm);
   const unsigned grid = (unsigned)(((int64_t)prm.batch + prm.games_per_block - 1) / prm.games_per_block);
   launch_prepare();
-  if (prm.mode == kModeStep)
+  if (prm.mode == kModeStep && (prm.class_out || (prm.stages & kStageFeatureSort)))
+    hipLaunchKernelGGL((fast_kernel<M, D, kModeStepAux>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
+                       prm.in_stride, prm.batch, prm.games_per_block, prm);
+  else if (prm.mode == kModeStep)
     hipLaunchKernelGGL((fast_kernel<M, D, kModeStep>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
                        prm.in_stride, prm.batch, prm.games_per_block, prm);
   else if (prm.mode == kModeRollout && (prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out ||

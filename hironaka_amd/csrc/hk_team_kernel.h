@@ -379,11 +379,14 @@ __device__ __forceinline__ void team_publish_ranked(const float (&q)[C * D], flo
   });
 }
 
-template <int D, int MODE>
+// ZEIL: the rollout variant whose host is Zeillinger's (its pair scan would otherwise sit in every rollout's
+// register budget)
+template <int D, int MODE, bool ZEIL = false>
 __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Params prm) {
   extern __shared__ __align__(16) unsigned char hk_smem[];
   float* lds = reinterpret_cast<float*>(hk_smem);
   constexpr int C = kTeamSlots;
+  constexpr bool kStep = MODE == kModeStep || MODE == kModeStepAux;  // Aux: features / Zeillinger's class
   const int lane = threadIdx.x;
   const int tl = lane & (kTeam - 1), tg = lane >> 2;
   const int m = prm.m, n_el = m * D, S = prm.lds_stride;
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
 #pragma unroll
   for (int k = 0; k < D; ++k) c[k] = 0.0f;
   RawActions<D> raw;
-  const bool fetch_actions = MODE == kModeStep && (stages & HK_STAGE_SHIFT) && active;
+  const bool fetch_actions = kStep && (stages & HK_STAGE_SHIFT) && active;
   if (fetch_actions) fast_fetch_actions<D>(prm, g, m, raw);  // converted after the slab is requested
 
   // ---- 1. the image --------------------------------------------------------------------------------
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
   if (!exact) {
     // ---- slow path (whole wave): the exact generic routines on the image, one lane per game ------
     float* cs = cbuf + tg * D;
-    if (MODE == kModeStep && prm.class_out) {  // hk_zeillinger: the class is the only output
+    if (MODE == kModeStepAux && prm.class_out) {  // hk_zeillinger: the class is the only output
       if (leader) prm.class_out[g] = zeillinger_game<float>(mine, m, prm.d);
       return;
     }
@@ -479,11 +482,11 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
           __syncthreads();
         }
         uint32_t mask;
-        const int zc = (prm.host_policy == HK_HOST_ZEILLINGER && leader) ? zeillinger_game<float>(mine, m, prm.d) : 0;
+        const int zc = (ZEIL && prm.host_policy == HK_HOST_ZEILLINGER && leader) ? zeillinger_game<float>(mine, m, prm.d) : 0;
         fast_policy<D>(prm, gg, prm.step_offset + (uint32_t)t, pcache, cls, axis, mask, zc);
         if (leader)
           for (int k = 0; k < D; ++k) cs[k] = (float)((mask >> k) & 1u);
-      } else if (MODE == kModeStep && (stages & HK_STAGE_SHIFT) && leader) {
+      } else if (kStep && (stages & HK_STAGE_SHIFT) && leader) {
         load_coords<float>(prm, g, cs);
         axis = axis_in;
       }
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
           const unsigned long long bd = __ballot(leader && done);
           if (lane == 0) count_add(prm.count_ws + (size_t)(t + 1) * gridDim.x + blockIdx.x, (uint32_t)__popcll(bd));
         }
-      } else if (MODE == kModeStep && leader) {
+      } else if (kStep && leader) {
         if (prm.done_out) prm.done_out[g] = done;
         if (prm.prev_done_out) prm.prev_done_out[g] = prev_done;
         if (prm.reward_out) prm.reward_out[g] = prm.reward_sign * (float)(done && !prev_done);
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
     np = 2;  // never "done", never counted
   }
   team_gather<D, C>(q, orig, mine, gmask, tl, smax, false);
-  if (MODE == kModeStep && prm.class_out) {  // hk_zeillinger: the class is the only output
+  if (MODE == kModeStepAux && prm.class_out) {  // hk_zeillinger: the class is the only output
     __syncthreads();
     team_mirror<D, C>(q, mine, tl, smax);
     __syncthreads();
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
       }
       uint32_t mask;
       int zc = 0;
-      if (prm.host_policy == HK_HOST_ZEILLINGER) {
+      if (ZEIL && prm.host_policy == HK_HOST_ZEILLINGER) {
         __syncthreads();
         team_mirror<D, C>(q, mine, tl, smax);
         __syncthreads();
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
       fast_policy<D>(prm, gg, prm.step_offset + (uint32_t)t, pcache, cls, axis, mask, zc);
 #pragma unroll
       for (int k = 0; k < D; ++k) c[k] = (float)((mask >> k) & 1u);
-    } else if (MODE == kModeStep) {
+    } else if (kStep) {
       axis = axis_in;
     }
     const bool prev_done = np < 2;
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
         smax = (nmax + kTeam - 1) / kTeam;
         team_gather<D, C>(q, orig, mine, gmask, tl, sprev, true);
       }
-    } else if (MODE == kModeStep && leader) {
+    } else if (kStep && leader) {
       if (prm.done_out) prm.done_out[g] = done;
       if (prm.prev_done_out) prm.prev_done_out[g] = prev_done;
       if (prm.reward_out) prm.reward_out[g] = prm.reward_sign * (float)(done && !prev_done);
@@ -627,7 +630,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
 
   // ---- 5. publish ----------------------------------------------------------------------------------
   __syncthreads();
-  if (MODE == kModeStep && (stages & kStageFeatureSort)) {
+  if (MODE == kModeStepAux && (stages & kStageFeatureSort)) {
     team_mirror<D, C>(q, mine, tl, smax);
     __syncthreads();
     team_publish_ranked<D, C>(q, mine, m, pad, tl, nmax, smax, active);
@@ -664,18 +667,22 @@ inline int plan_team(Params& prm) {
   return HK_OK;
 }
 
-template <int D, int MODE>
+template <int D, int MODE, bool ZEIL = false>
 int launch_team_t(const Params& prm, hipStream_t stream) {
   const size_t lds = (size_t)(prm.lds_stride + prm.d) * kTeamGames * sizeof(float);
   const unsigned grid = (unsigned)(((int64_t)prm.batch + kTeamGames - 1) / kTeamGames);
   launch_prepare();
-  hipLaunchKernelGGL((team_kernel<D, MODE>), dim3(grid), dim3(kWave), lds, stream, prm);
+  hipLaunchKernelGGL((team_kernel<D, MODE, ZEIL>), dim3(grid), dim3(kWave), lds, stream, prm);
   return launch_status();
 }
 
 template <int D>
 int launch_team_d(const Params& prm, hipStream_t stream) {
+  if (prm.mode == kModeStep && (prm.class_out || (prm.stages & kStageFeatureSort)))
+    return launch_team_t<D, kModeStepAux>(prm, stream);
   if (prm.mode == kModeStep) return launch_team_t<D, kModeStep>(prm, stream);
+  if (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER)
+    return launch_team_t<D, kModeRollout, true>(prm, stream);
   if (prm.mode == kModeRollout) return launch_team_t<D, kModeRollout>(prm, stream);
   return launch_team_t<D, kModeGenerate>(prm, stream);
 }
