@@ -76,6 +76,36 @@ def test_argument_validation_without_gpu():
     assert L.hk_has_fast_path(20, 3, A.HK_F32) == 1 and L.hk_has_fast_path(21, 3, A.HK_F32) == 0
 
 
+def test_rollout_and_search_validation_without_gpu():
+    """the rollout / deferred-count / search entry points refuse bad descriptors on the host"""
+    L = _lib.lib()
+    r = A.hk_rollout_desc()
+    r.batch, r.max_points, r.dim, r.dtype, r.steps = 64, 20, 3, A.HK_F32, 5
+    assert L.hk_rollout(ctypes.byref(r), None) == A.HK_ERR_NULL          # no state
+    assert L.hk_rollout_reduce_counts(ctypes.byref(r), None) == A.HK_ERR_NULL   # no workspace / done_count
+    assert L.hk_rollout_reduce_counts(None, None) == A.HK_ERR_NULL
+    r.steps = -1
+    assert L.hk_rollout(ctypes.byref(r), None) == A.HK_ERR_SHAPE
+    r.steps, r.batch = 5, 0
+    assert L.hk_rollout(ctypes.byref(r), None) == A.HK_OK                # empty batch: nothing to do
+    r.batch = 64
+    assert L.hk_rollout_workspace_bytes(ctypes.byref(r)) == 0            # invalid descriptor (no state)
+    buf = (ctypes.c_uint8 * 64)()
+    r.points = ctypes.addressof(buf)
+    need = L.hk_rollout_workspace_bytes(ctypes.byref(r))
+    assert need == 1 * 6 * 4                                             # one workgroup x (steps + 1) counters
+    r.flags = A.HK_FLAG_DEFER_COUNTS
+    assert L.hk_rollout(ctypes.byref(r), None) == A.HK_ERR_NULL          # deferred counts need the workspace
+    t = A.hk_search_tree()
+    t.batch, t.num_nodes, t.num_actions = 8, 9, 4
+    assert L.hk_search_policy(ctypes.byref(t), None, None, None, None, None) == A.HK_ERR_NULL
+    t.num_actions = 33
+    assert L.hk_search_policy(ctypes.byref(t), None, None, None, None, None) == A.HK_ERR_SHAPE
+    t.num_actions, t.batch = 4, 0
+    assert L.hk_search_select(ctypes.byref(t), None, None, None, 4, 8, 8, 1, None, None, None, None) == A.HK_OK
+    assert L.hk_search_backup(None, None, None, None, None, None, None, None, None) == A.HK_ERR_NULL
+
+
 def test_product_never_touches_the_oracle():
     pkg = os.path.join(ROOT, "hironaka_amd")
     for dirpath, _, files in os.walk(pkg):
