@@ -344,8 +344,13 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   const unsigned flags = HOT ? (unsigned)HK_SEM_JAX : prm.flags;
   const unsigned stages = HOT ? (unsigned)(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON)
                               : (MODE == kModeGenerate) ? (prm.stages & ~HK_STAGE_SHIFT) : prm.stages;
-  const float fill = ((flags & HK_SEM_MASK) == HK_SEM_TORCH) ? pad : -1.0f;
+  const float fill = ((flags & HK_SEM_MASK) == HK_SEM_JAX) ? -1.0f : pad;  // _jax_ops.py:65 does not forward pad
   const int nsteps = (kRoll) ? prm.steps : 1;
+  // list semantics / COMPACT_SORTED: every Newton stage leaves the state sorted (descending lexicographic)
+  // and compacted.  Only the variants that are off the hot paths carry the code.
+  constexpr bool kSortedCapable = MODE == kModeStepAux || MODE == kModeRolloutRec;
+  const bool sorted_out = kSortedCapable && (stages & HK_STAGE_NEWTON) &&
+                          ((flags & HK_SEM_MASK) == HK_SEM_LIST || (flags & HK_FLAG_COMPACT_SORTED));
   PolicyCache pcache;
 
   // step mode: the action loads join the slab's requests in flight
@@ -504,7 +509,24 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
     }
     const bool prev_done = np < 2;
 
-    np = run_stages<G::C, D>(q, nmax, c, axis, np, flags, stages);  // branch-free body for >= nmax rows
+    if (sorted_out) {
+      // list semantics: right after the Newton stage (before a rescale could round two keys together) the
+      // survivors are sorted descending-lexicographically and packed to the front -- physically: rows to
+      // their rank in the image, slots 0..n-1 become the game's live slots, registers re-gathered in that order
+      np = run_stages<G::C, D>(q, nmax, c, axis, np, flags, stages & ~(unsigned)HK_STAGE_RESCALE);
+      int rank[G::C];
+      feature_ranks<G::C, D, true>(q, nmax, rank);
+      __syncthreads();
+      scatter_ranked<G::C, D>(q, mine, rank, nmax);
+      __syncthreads();
+      gmask = (np >= (int)(8 * sizeof(MaskT<M>))) ? ~(MaskT<M>)0 : (((MaskT<M>)1 << np) - 1);
+      const int nprev = nmax;
+      nmax = wave_max(active ? np : 0, nmax);
+      gather_rows<M, G::C, D>(q, mine, gmask, nprev);
+      if (stages & HK_STAGE_RESCALE) np = run_stages<G::C, D>(q, nmax, c, axis, np, flags, HK_STAGE_RESCALE);
+    } else {
+      np = run_stages<G::C, D>(q, nmax, c, axis, np, flags, stages);  // branch-free body for >= nmax rows
+    }
     if (!active) np = 2;
     const bool done = np < 2;
     if (done && length < 0) length = t + 1;
@@ -607,14 +629,16 @@ int launch_fast_t(Params prm, hipStream_t stream) {
   prm.games_per_block = fast_games_per_block(prm);
   const unsigned grid = (unsigned)(((int64_t)prm.batch + prm.games_per_block - 1) / prm.games_per_block);
   launch_prepare();
-  if (prm.mode == kModeStep && (prm.class_out || (prm.stages & kStageFeatureSort)))
+  const bool sorted_out = (prm.stages & HK_STAGE_NEWTON) &&
+                          ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED));
+  if (prm.mode == kModeStep && (prm.class_out || (prm.stages & kStageFeatureSort) || sorted_out))
     hipLaunchKernelGGL((fast_kernel<M, D, kModeStepAux>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
                        prm.in_stride, prm.batch, prm.games_per_block, prm);
   else if (prm.mode == kModeStep)
     hipLaunchKernelGGL((fast_kernel<M, D, kModeStep>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
                        prm.in_stride, prm.batch, prm.games_per_block, prm);
-  else if (prm.mode == kModeRollout && (prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out ||
-                                        prm.r_reward_out))
+  else if (prm.mode == kModeRollout && (sorted_out || prm.obs_out || prm.r_host_class_out || prm.r_axis_out ||
+                                        prm.r_done_out || prm.r_reward_out))
     hipLaunchKernelGGL((fast_kernel<M, D, kModeRolloutRec>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
                        prm.in_stride, prm.batch, prm.games_per_block, prm);
   else if (prm.mode == kModeRollout && fast_hot_config(prm))
@@ -632,7 +656,13 @@ int launch_fast_t(Params prm, hipStream_t stream) {
 // does this request run on a register-resident specialisation? (else: generic kernel)
 inline bool fast_supported(const Params& prm, int dtype) {
   if (dtype != HK_F32) return false;
-  if ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)) return false;
+  // sorted + compacted output (list semantics): not from the generator, and not under Zeillinger's host,
+  // whose tie-breaks follow the physical row order
+  const bool sorted_out = (prm.stages & HK_STAGE_NEWTON) &&
+                          ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED));
+  if (sorted_out && (prm.mode == kModeGenerate ||
+                     (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER)))
+    return false;
   if (prm.flags & (HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_TEAM)) return false;
   if ((prm.stages & kStageFeatureSort) && prm.mode != kModeStep) return false;
   if (prm.mode == kModeZeillinger) return false;

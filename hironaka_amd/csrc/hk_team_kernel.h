@@ -337,13 +337,12 @@ __device__ __forceinline__ int team_zeillinger(const float (&q)[C * D], const fl
   return encode_mask((1u << lo) | (1u << hi));
 }
 
-// observation features (jax/util.py:186-197): the team's live rows at their rank in descending key order
-// (last coordinate primary; equal keys are equal rows), padding behind them.  The region must hold the
-// mirror of the rows; rank = number of live rows j that come before row i.
-template <int D, int C>
-__device__ __forceinline__ void team_publish_ranked(const float (&q)[C * D], float* mine, int m, float pad, int tl,
-                                                    int nmax, int smax, bool active) {
-  int rank[C];
+// rank of each of the lane's rows among the team's live rows in descending key order (FIRST: coordinate 0
+// primary -- the list semantics' lexicographic order; otherwise the last -- the features' lexsort; equal
+// keys are equal rows, the lower index first).  The region must hold the mirror of the rows.
+template <int D, int C, bool FIRST>
+__device__ __forceinline__ void team_ranks(const float (&q)[C * D], const float* mine, int tl, int nmax, int smax,
+                                           int (&rank)[C]) {
 #pragma unroll
   for (int s = 0; s < C; ++s) rank[s] = 0;
   for (int j = 0; j < nmax; ++j) {
@@ -353,19 +352,19 @@ __device__ __forceinline__ void team_publish_ranked(const float (&q)[C * D], flo
     unrolled_while<0, C>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
       if (s >= smax) return false;
-      const bool j_greater = key_gt<D>(pj, &q[s * D]);
-      const bool i_greater = key_gt<D>(&q[s * D], pj);
+      const bool j_greater = key_gt<D, FIRST>(pj, &q[s * D]);
+      const bool i_greater = key_gt<D, FIRST>(&q[s * D], pj);
       const bool before = live_j && (j_greater || (!i_greater && j < kTeam * s + tl));
       rank[s] += before ? 1 : 0;
       return true;
     });
   }
-  __syncthreads();
-  float pv[D];
-#pragma unroll
-  for (int k = 0; k < D; ++k) pv[k] = pad;
-  if (active)
-    for (int i = tl; i < m; i += kTeam) row_store<D>(mine + i * D, pv);
+}
+
+// the lane's live rows to their rank in the region
+template <int D, int C>
+__device__ __forceinline__ void team_scatter_ranked(const float (&q)[C * D], float* mine, const int (&rank)[C],
+                                                    int smax) {
   unrolled_while<0, C>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
     if (s >= smax) return false;
@@ -377,6 +376,21 @@ __device__ __forceinline__ void team_publish_ranked(const float (&q)[C * D], flo
     }
     return true;
   });
+}
+
+// observation features (jax/util.py:186-197): pad everywhere, the live rows at their rank
+template <int D, int C>
+__device__ __forceinline__ void team_publish_ranked(const float (&q)[C * D], float* mine, int m, float pad, int tl,
+                                                    int nmax, int smax, bool active) {
+  int rank[C];
+  team_ranks<D, C, false>(q, mine, tl, nmax, smax, rank);
+  __syncthreads();
+  float pv[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) pv[k] = pad;
+  if (active)
+    for (int i = tl; i < m; i += kTeam) row_store<D>(mine + i * D, pv);
+  team_scatter_ranked<D, C>(q, mine, rank, smax);
 }
 
 // ZEIL: the rollout variant whose host is Zeillinger's (its pair scan would otherwise sit in every rollout's
@@ -402,7 +416,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
   const float pad = (float)prm.pad;
   const unsigned flags = prm.flags;
   const unsigned stages = (MODE == kModeGenerate) ? (prm.stages & ~HK_STAGE_SHIFT) : prm.stages;
-  const float fill = ((flags & HK_SEM_MASK) == HK_SEM_TORCH) ? pad : -1.0f;
+  const float fill = ((flags & HK_SEM_MASK) == HK_SEM_JAX) ? -1.0f : pad;  // _jax_ops.py:65 does not forward pad
   const int nsteps = (MODE == kModeRollout) ? prm.steps : 1;
   const bool vec_in = (n_el % 4 == 0) && (prm.in_stride % 4 == 0) && prm.in &&
                       (reinterpret_cast<uintptr_t>(prm.in) % 16 == 0);
@@ -580,6 +594,25 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
       const Mask64 dead = team_newton<D, C>(q, orig, mine, tl, nmax, smax);
       gmask &= ~dead;
       if (active) np = __popcll(gmask);
+      if (MODE == kModeStepAux && ((flags & HK_SEM_MASK) == HK_SEM_LIST || (flags & HK_FLAG_COMPACT_SORTED))) {
+        // list semantics: right after the Newton stage (before a rescale could round two keys together) the
+        // survivors are sorted descending-lexicographically and packed to the front -- physically: rows to
+        // their rank in the region, slots 0..n-1 become the game's live slots, registers re-gathered
+        __syncthreads();
+        team_mirror<D, C>(q, mine, tl, smax);
+        __syncthreads();
+        int rank[C];
+        team_ranks<D, C, true>(q, mine, tl, nmax, smax, rank);
+        __syncthreads();
+        team_scatter_ranked<D, C>(q, mine, rank, smax);
+        __syncthreads();
+        const int live = active ? np : 0;
+        gmask = live >= 64 ? ~(Mask64)0 : (((Mask64)1 << live) - 1);
+        const int sprev = smax;
+        nmax = wave_max(live, nmax);
+        smax = (nmax + kTeam - 1) / kTeam;
+        team_gather<D, C>(q, orig, mine, gmask, tl, sprev, true);
+      }
     }
     if (stages & HK_STAGE_RESCALE) team_rescale<D, C>(q, smax, flags);
 
@@ -645,7 +678,10 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
 // HK_FLAG_FORCE_TEAM puts the shapes that have a register-resident specialisation on this kernel too
 inline bool team_supported(const Params& prm, int dtype) {
   if (dtype != HK_F32) return false;
-  if ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)) return false;
+  // sorted + compacted output (list semantics): single steps only
+  if ((prm.stages & HK_STAGE_NEWTON) && prm.mode != kModeStep &&
+      ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)))
+    return false;
   if (prm.flags & HK_FLAG_FORCE_GENERIC) return false;
   if ((prm.stages & kStageFeatureSort) && prm.mode != kModeStep) return false;
   if (prm.mode == kModeZeillinger) return false;
@@ -678,7 +714,9 @@ int launch_team_t(const Params& prm, hipStream_t stream) {
 
 template <int D>
 int launch_team_d(const Params& prm, hipStream_t stream) {
-  if (prm.mode == kModeStep && (prm.class_out || (prm.stages & kStageFeatureSort)))
+  const bool sorted_out = (prm.stages & HK_STAGE_NEWTON) &&
+                          ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED));
+  if (prm.mode == kModeStep && (prm.class_out || (prm.stages & kStageFeatureSort) || sorted_out))
     return launch_team_t<D, kModeStepAux>(prm, stream);
   if (prm.mode == kModeStep) return launch_team_t<D, kModeStep>(prm, stream);
   if (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER)

@@ -36,7 +36,7 @@ def main():
             d = int(rng.integers(2, 7))
             m = int(rng.integers(2, 65))
         b = int(rng.choice([1, 15, 16, 17, 63, 64, 65, 200, 1000, 3000]))
-        sem = ["jax", "torch"][rng.integers(0, 2)]
+        sem = ["jax", "torch", "list"][rng.integers(0, 3)]
         pad = float(rng.choice([-1.0, -1.0, -1.0, -1e-8, -2.5]))
         force = int(rng.choice([0, 0, A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC]))
         noop, ign = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
@@ -52,8 +52,10 @@ def main():
             p[2, 0, 0] = -0.5
         cfg = dict(m=m, d=d, b=b, sem=sem, pad=pad, force=force, noop=noop, ign=ign, stages=stages, maxv=maxv,
                    holes=holes)
-        flags_o = CO.flags_of(sem=sem, noop_if_invalid=noop, ignore_ended=ign)
-        flags_p = ops.make_flags(sem, noop, ign) | force
+        compact = bool(rng.integers(0, 4) == 0)
+        cfg["compact"] = compact
+        flags_o = CO.flags_of(sem=sem, noop_if_invalid=noop, ignore_ended=ign, compact_sorted=compact)
+        flags_p = ops.make_flags(sem, noop, ign, compact_sorted=compact) | force
         cls = rng.integers(0, 2 ** d - d - 1, b).astype(np.int64)
         ax = rng.integers(0, d, b).astype(np.int32)
         P = torch.as_tensor(p).cuda()
@@ -85,6 +87,10 @@ def main():
         for k in ("obs", "host_class", "axis", "done", "reward", "game_length"):
             if not np.array_equal(rec[k].cpu().numpy(), wrec[k]):
                 print("ROLLOUT MISMATCH", k, cfg)
+                dump = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+                os.makedirs(dump, exist_ok=True)
+                np.savez(os.path.join(dump, "fuzz_mismatch.npz"), p=p, got=rec[k].cpu().numpy(), want=wrec[k],
+                         got_final=Q.cpu().numpy(), want_final=wp)
                 sys.exit(1)
         if not np.array_equal(rec["done_count"].cpu().numpy().astype(np.uint64), wrec["done_count"]):
             print("ROLLOUT MISMATCH done_count", cfg)
