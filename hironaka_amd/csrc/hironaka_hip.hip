@@ -454,9 +454,9 @@ int hk_zeillinger(const void* points, int64_t stride, int32_t* class_out, int ba
   prm.m = max_points;
   prm.d = dim;
   prm.mode = kModeZeillinger;
-  // JAX variant on the register-resident / team kernels: a step launch without stages and without a state
-  // output, whose only product is class_out
-  if ((flags & HK_SEM_MASK) == HK_SEM_JAX && !(flags & HK_FLAG_FORCE_GENERIC)) {
+  // on the register-resident / team kernels: a step launch without stages and without a state output, whose
+  // only product is class_out (both variants: the semantics code travels in the flags)
+  if (!(flags & HK_FLAG_FORCE_GENERIC)) {
     Params fast = prm;
     fast.mode = kModeStep;
     fast.pad = -1.0;

@@ -395,7 +395,9 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
     // ---- slow path (whole wave): the exact generic routines on the image ------------------------
     float* cs = cbuf + lane * D;
     if (MODE == kModeStepAux && prm.class_out) {  // hk_zeillinger: the class is the only output
-      if (active) prm.class_out[g] = zeillinger_game<float>(mine, prm.m, prm.d);
+      if (active)
+        prm.class_out[g] = ((flags & HK_SEM_MASK) == HK_SEM_LIST) ? zeillinger_list_game<float>(mine, prm.m, prm.d)
+                                                                  : zeillinger_game<float>(mine, prm.m, prm.d);
       return;
     }
     np = active ? num_points<float>(mine, M, D) : 2;
@@ -457,7 +459,9 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   for (int e = 0; e < G::C * D; ++e) q[e] = INFINITY;  // rows past nmax are holes in the straight-line bodies
   gather_rows<M, G::C, D>(q, mine, gmask, nmax);
   if (MODE == kModeStepAux && prm.class_out) {  // hk_zeillinger: the class is the only output
-    if (active) prm.class_out[g] = c_zeillinger<G::C, D>(q, nmax);
+    if (active)
+      prm.class_out[g] = ((flags & HK_SEM_MASK) == HK_SEM_LIST) ? c_zeillinger<G::C, D, true>(q, nmax)
+                                                                : c_zeillinger<G::C, D>(q, nmax);
     return;
   }
   if (!active) np = 2;  // never "done", never counted

@@ -408,7 +408,10 @@ __device__ __forceinline__ void scatter_ranked(const float (&q)[C * D], float* m
 // (L, S) in row-major order wins -- among ordered pairs that is always an (i, j) with i < j, and the
 // compaction keeps the rows' order, so the triangle i < j in compact order finds the same pair.  The
 // subset is {argmin, argmax} of that difference; no valid pair -> class 0 (players.py:96-109).
-template <int C, int D>
+// LIST: Zeillinger._select_coord (host.py:70-95) instead -- every pair of available rows counts (no isclose
+// filter), the rows are in the state's physical order (which the gather keeps), a game with fewer than two
+// rows gives -1 and coinciding argmin / argmax the subset {0, 1}.
+template <int C, int D, bool LIST = false>
 __device__ __forceinline__ int c_zeillinger(const float (&q)[C * D], int nmax) {
   float bestL = INFINITY, bestS = INFINITY;
   float bd[D];
@@ -436,8 +439,8 @@ __device__ __forceinline__ int c_zeillinger(const float (&q)[C * D], int nmax) {
 #pragma unroll
       for (int k = 0; k < D; ++k) cnt += (float)((v[k] == mx) + (v[k] == mn));
       const float L = mx - mn;
-      const bool valid = live_i && (q[j * D] < INFINITY) && !close;
-      const bool better = valid && (L < bestL || (L == bestL && cnt < bestS));
+      const bool valid = live_i && (q[j * D] < INFINITY) && (LIST || !close);
+      const bool better = valid && ((LIST && !have) || L < bestL || (L == bestL && cnt < bestS));
       bestL = better ? L : bestL;
       bestS = better ? cnt : bestS;
 #pragma unroll
@@ -453,6 +456,10 @@ __device__ __forceinline__ int c_zeillinger(const float (&q)[C * D], int nmax) {
   for (int k = 1; k < D; ++k) {
     if (bd[k] < vlo) { vlo = bd[k]; lo = k; }
     if (bd[k] > vhi) { vhi = bd[k]; hi = k; }
+  }
+  if (LIST) {
+    if (!have) return -1;
+    return (lo == hi) ? encode_mask(3u) : encode_mask((1u << lo) | (1u << hi));
   }
   if (!have || lo == hi) return 0;
   return encode_mask((1u << lo) | (1u << hi));

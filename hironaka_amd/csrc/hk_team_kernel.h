@@ -268,7 +268,8 @@ __device__ __forceinline__ void team_publish(const float (&q)[C * D], const uint
 // i*64 + j makes "first minimum in row-major order" independent of the order in which the lanes visit the
 // pairs -- and two DPP exchanges leave the team's best pair, with its difference vector, in every lane.
 // The region must hold the mirror of the team's rows.
-template <int D, int C>
+// LIST: the list variant (see c_zeillinger)
+template <int D, int C, bool LIST = false>
 __device__ __forceinline__ int team_zeillinger(const float (&q)[C * D], const float* mine, int tl, int nmax, int smax) {
   float bestL = INFINITY, bestS = INFINITY;
   int bestP = 0x7FFFFFFF;
@@ -298,7 +299,7 @@ __device__ __forceinline__ int team_zeillinger(const float (&q)[C * D], const fl
       for (int k = 0; k < D; ++k) cnt += (float)((v[k] == mx) + (v[k] == mn));
       const float L = mx - mn;
       const int pos = i * 64 + j;
-      const bool valid = (i < j) && live_j && (q[s * D] < INFINITY) && !close;
+      const bool valid = (i < j) && live_j && (q[s * D] < INFINITY) && (LIST || !close);
       const bool better = valid && (L < bestL || (L == bestL && (cnt < bestS || (cnt == bestS && pos < bestP))));
       bestL = better ? L : bestL;
       bestS = better ? cnt : bestS;
@@ -332,6 +333,10 @@ __device__ __forceinline__ int team_zeillinger(const float (&q)[C * D], const fl
   for (int k = 1; k < D; ++k) {
     if (bd[k] < vlo) { vlo = bd[k]; lo = k; }
     if (bd[k] > vhi) { vhi = bd[k]; hi = k; }
+  }
+  if (LIST) {
+    if (bestP == 0x7FFFFFFF) return -1;
+    return (lo == hi) ? encode_mask(3u) : encode_mask((1u << lo) | (1u << hi));
   }
   if (bestP == 0x7FFFFFFF || lo == hi) return 0;
   return encode_mask((1u << lo) | (1u << hi));
@@ -477,7 +482,9 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
     // ---- slow path (whole wave): the exact generic routines on the image, one lane per game ------
     float* cs = cbuf + tg * D;
     if (MODE == kModeStepAux && prm.class_out) {  // hk_zeillinger: the class is the only output
-      if (leader) prm.class_out[g] = zeillinger_game<float>(mine, m, prm.d);
+      if (leader)
+        prm.class_out[g] = ((flags & HK_SEM_MASK) == HK_SEM_LIST) ? zeillinger_list_game<float>(mine, m, prm.d)
+                                                                  : zeillinger_game<float>(mine, m, prm.d);
       return;
     }
     np = leader ? num_points<float>(mine, m, D) : 2;
@@ -548,7 +555,8 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
     __syncthreads();
     team_mirror<D, C>(q, mine, tl, smax);
     __syncthreads();
-    const int zc = team_zeillinger<D, C>(q, mine, tl, nmax, smax);
+    const int zc = ((flags & HK_SEM_MASK) == HK_SEM_LIST) ? team_zeillinger<D, C, true>(q, mine, tl, nmax, smax)
+                                                          : team_zeillinger<D, C>(q, mine, tl, nmax, smax);
     if (leader) prm.class_out[g] = zc;
     return;
   }

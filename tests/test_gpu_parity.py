@@ -617,17 +617,19 @@ def test_zeillinger_operator_matches_oracle(spec):
     p[1, 1:] = -1.0
     g = host(ops.generate_points(b, m, d, 20, seed=9))
     frac = np.where(g >= 0, g / np.float32(7.0), g).astype(np.float32)
-    for states in (p, g, frac):
-        want = CO.zeillinger(states, "jax")
-        assert np.array_equal(host(ops.zeillinger(dev(states))), want)
-        assert np.array_equal(host(ops.zeillinger(dev(states), force_generic=True)), want)
-        if d <= 6 and m <= 64:
-            assert np.array_equal(host(ops.zeillinger(dev(states), force_team=True)), want)
+    for sem in ("jax", "list"):
+        for states in (p, g, frac):
+            want = CO.zeillinger(states, sem)
+            assert np.array_equal(host(ops.zeillinger(dev(states), sem)), want), sem
+            assert np.array_equal(host(ops.zeillinger(dev(states), sem, force_generic=True)), want), sem
+            if d <= 6 and m <= 64:
+                assert np.array_equal(host(ops.zeillinger(dev(states), sem, force_team=True)), want), sem
     r = p.copy()
     if m >= 3:
         r[7, 1] = -3.0
         r[8, 0, 0] = -0.5
-    assert np.array_equal(host(ops.zeillinger(dev(r))), CO.zeillinger(r, "jax"))
+    for sem in ("jax", "list"):
+        assert np.array_equal(host(ops.zeillinger(dev(r), sem)), CO.zeillinger(r, sem)), sem
     # records with a stride (agent observations) and a ragged batch
     rec = np.concatenate([g.reshape(b, m * d), np.ones((b, d), np.float32)], axis=1)[:333]
     assert np.array_equal(host(ops.zeillinger(dev(rec), spec=spec)), CO.zeillinger(g[:333], "jax"))
