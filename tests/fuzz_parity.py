@@ -20,6 +20,45 @@ from oracle import c_oracle as CO
 FAST = [(4, 3), (5, 3), (10, 3), (16, 3), (20, 3), (8, 4), (20, 4)]
 
 
+def operator_case(rng):
+    """the two state-reading operators: Zeillinger's class (both variants, every kernel family) and the sorted
+    observation features"""
+    if rng.integers(0, 2) == 0:
+        m, d = FAST[rng.integers(0, len(FAST))]
+    else:
+        d = int(rng.integers(2, 8))
+        m = int(rng.integers(2, 65))
+    b = int(rng.choice([1, 63, 65, 200, 513]))
+    kind = int(rng.integers(4))
+    cfg = dict(op=1, m=m, d=d, b=b, kind=kind)
+    p = rng.integers(0, int(rng.choice([2, 3, 6, 20])), (b, m, d)).astype(np.float32)
+    p[rng.random((b, m)) < float(rng.choice([0.0, 0.3, 0.8, 0.97]))] = -1.0
+    if kind == 1:  # dyadic fractions: ties in (L, S) that survive a rescale
+        p = np.where(p >= 0, p / np.float32(4.0), p).astype(np.float32)
+    elif kind == 2:  # thirds: the isclose filter and rounding in the differences
+        p = np.where(p >= 0, p / np.float32(3.0), p).astype(np.float32)
+    elif kind == 3 and b > 4 and m > 2:  # irregular rows: the exact path
+        p[3, 1] = -3.0
+        p[2, 0, 0] = -0.5
+    P = torch.as_tensor(p).cuda()
+    force = [{}, {"force_generic": True}]
+    if m <= 64 and d <= 6:
+        force.append({"force_team": True})
+    for sem in ("jax", "list"):
+        want = CO.zeillinger(p, sem)
+        for kw in force:
+            if not np.array_equal(ops.zeillinger(P, sem, **kw).cpu().numpy(), want):
+                print("ZEILLINGER MISMATCH", dict(cfg, sem=sem, **kw))
+                sys.exit(1)
+    if kind != 3:
+        for scale in (True, False):
+            want = CO.get_features(p, scale)
+            got = ops.get_features(P, scale_observation=scale).cpu().numpy()
+            if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
+                print("FEATURES MISMATCH", dict(cfg, scale=scale))
+                sys.exit(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=2.0)
@@ -29,6 +68,10 @@ def main():
     t_end = time.time() + 60 * args.minutes
     n = 0
     while time.time() < t_end:
+        if rng.integers(0, 8) == 0:
+            operator_case(rng)
+            n += 1
+            continue
         kind = rng.integers(0, 3)
         if kind == 0:
             m, d = FAST[rng.integers(0, len(FAST))]
