@@ -147,6 +147,7 @@ PROTOTYPES = {
     "hk_search_policy": (C.c_int, [C.POINTER(hk_search_tree), _vp, _vp, _vp, _vp, _vp]),
     "hk_zeillinger": (C.c_int, [_vp, _i64, _vp, _i, _i, _i, _i, _u32, _vp]),
     "hk_get_features": (C.c_int, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _d, _vp]),
+    "hk_get_features_torch": (C.c_int, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _d, _vp]),
     "hk_decode_host_class": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
 }
 

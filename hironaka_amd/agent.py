@@ -25,7 +25,7 @@ class Agent(abc.ABC):
         actions = torch.where(coords.sum(dim=1) > 1, actions, torch.full_like(actions, -1))
         if not inplace:
             return actions
-        flags = ops.make_flags(sem, noop_if_invalid=True)
+        flags = ops.make_flags(getattr(points, "semantics", sem), noop_if_invalid=True)
         stages = ops.make_stages(True, self.USE_REPOSITION, True, False)
         pad = getattr(points, "padding_value", -1.0)
         res = ops.step(pts, coords, actions, stages=stages, flags=flags, padding_value=pad, out=pts)

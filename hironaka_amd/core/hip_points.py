@@ -8,6 +8,11 @@ torch sibling: an axis outside the host's subset and (by default) a finished gam
     FusedGame.agent_move (trainer/fused_game.py:150-163):
         points.shift(host_moves, actions); points.get_newton_polytope(); points.rescale()
     costs three launches here; ``points.step(host_moves, actions, rescale=True)`` fuses them.
+
+``semantics="list"`` turns the container into the padded form of ``ListPoints``
+(hironaka/core/list_points.py:20-135): the Newton polytope comes out sorted (descending, coordinate 0
+primary) and compacted to the front (_list_ops.py:25-41), which is what ``GameHironaka`` and the gym
+environments step.
 """
 from typing import List, Optional, Type, Union
 
@@ -30,13 +35,16 @@ def _pad_ragged(points, new_length: int, constant_value: float) -> np.ndarray:
 
 
 class HipPoints(PointsBase):
-    subcls_config_keys = ["value_threshold", "device", "padding_value", "dtype"]
+    subcls_config_keys = ["value_threshold", "device", "padding_value", "dtype", "semantics"]
     running_attributes = ["distinguished_points"]
 
     def __init__(self, points: Union[torch.Tensor, List[List[List[float]]], np.ndarray],
                  value_threshold: Optional[float] = 1e8, device: Optional[Union[str, torch.device]] = "cuda",
                  padding_value: Optional[float] = -1.0, distinguished_points: Optional[List[int]] = None,
-                 dtype: Optional[Union[Type, torch.dtype]] = torch.float32, **kwargs):
+                 dtype: Optional[Union[Type, torch.dtype]] = torch.float32, semantics: str = "torch", **kwargs):
+        if semantics not in ("torch", "list"):
+            raise ValueError(f"semantics must be 'torch' or 'list'. Got {semantics}.")
+        self.semantics = semantics
         assert padding_value <= 0.0, f"'padding_value' must be a non-positive number. Got {padding_value} instead."
         self.value_threshold = value_threshold
         self.dtype = dtype
@@ -67,8 +75,7 @@ class HipPoints(PointsBase):
 
     def get_features(self) -> torch.Tensor:
         """rows sorted by coordinate 0, descending (tensor_points.py:72-74)"""
-        order = torch.argsort(self.points[:, :, 0], dim=1, descending=True, stable=True)
-        return self.points.gather(1, order.unsqueeze(-1).expand(-1, -1, self.dimension)).clone()
+        return ops.get_features_torch(self.points, self.padding_value)
 
     def type(self, t: Union[Type, torch.dtype]):
         self.dtype = t
@@ -88,7 +95,7 @@ class HipPoints(PointsBase):
              ignore_ended_games: bool = True, want=()):
         """shift -> [reposition] -> newton -> [rescale] in ONE launch, in place."""
         coords, axis = self._actions(coords, axis)
-        flags = ops.make_flags("torch", noop_if_invalid=True, ignore_ended=ignore_ended_games)
+        flags = ops.make_flags(self.semantics, noop_if_invalid=True, ignore_ended=ignore_ended_games)
         stages = ops.make_stages(True, reposition, True, rescale)
         work, back = self._work()
         res = ops.step(work, coords, axis, stages=stages, flags=flags, padding_value=self.padding_value,
@@ -124,7 +131,7 @@ class HipPoints(PointsBase):
         return coords.to(self.device), axis.to(self.device)
 
     def _op(self, points, inplace, stages, coords=None, axis=None, flags=None):
-        flags = ops.make_flags("torch") if flags is None else flags
+        flags = ops.make_flags(self.semantics) if flags is None else flags
         if inplace and points is self.points:
             work, back = self._work()
             ops.step(work, coords, axis, stages=stages, flags=flags, padding_value=self.padding_value, out=work)
@@ -135,7 +142,7 @@ class HipPoints(PointsBase):
     def _shift(self, points, coords, axis, inplace: Optional[bool] = True, ignore_ended_games: Optional[bool] = True,
                **kwargs):
         coords, axis = self._actions(coords, axis)
-        flags = ops.make_flags("torch", noop_if_invalid=True, ignore_ended=ignore_ended_games)
+        flags = ops.make_flags(self.semantics, noop_if_invalid=True, ignore_ended=ignore_ended_games)
         return self._op(points, inplace, A.HK_STAGE_SHIFT, coords, axis, flags)
 
     def _get_newton_polytope(self, points, inplace: Optional[bool] = True, **kwargs):

@@ -106,7 +106,7 @@ int params_from_step(const hk_step_desc* s, Params& prm) {
   if (s->in_stride < n || s->out_stride < n) return HK_ERR_SHAPE;
   const size_t es = elem_size(s->dtype);
   if (!aligned(s->points_in, es) || !aligned(s->points_out, es)) return HK_ERR_ALIGN;
-  if (s->stages & ~(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON | HK_STAGE_RESCALE | kStageFeatureSort))
+  if (s->stages & ~(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON | HK_STAGE_RESCALE | kStageFeatureSorts))
     return HK_ERR_UNSUPPORTED;
   if ((s->flags & HK_SEM_MASK) == HK_SEM_MASK) return HK_ERR_UNSUPPORTED;
   prm = Params{};
@@ -474,6 +474,18 @@ int hk_get_features(const void* points_in, int64_t in_stride, void* features_out
                     int scale_observation, double padding_value, void* stream) {
   hk_step_desc s = plain_desc(points_in, features_out, batch, max_points, dim, dtype, padding_value,
                               (scale_observation ? HK_STAGE_RESCALE : 0u) | kStageFeatureSort, HK_SEM_JAX);
+  s.in_stride = in_stride;
+  s.out_stride = out_stride;
+  Params prm{};
+  const int st = params_from_step(&s, prm);
+  if (st != HK_OK) return st;
+  return launch(prm, dtype, (hipStream_t)stream);
+}
+
+int hk_get_features_torch(const void* points_in, int64_t in_stride, void* features_out, int64_t out_stride,
+                          int batch, int max_points, int dim, int dtype, double padding_value, void* stream) {
+  hk_step_desc s = plain_desc(points_in, features_out, batch, max_points, dim, dtype, padding_value,
+                              kStageFeatureSort0, HK_SEM_TORCH);
   s.in_stride = in_stride;
   s.out_stride = out_stride;
   Params prm{};

@@ -14,7 +14,16 @@ constexpr int kMaxLdsBytes = 160 * 1024;  // one workgroup may own the CU's whol
 constexpr int kMaxDim = 30;               // subsets travel as 32-bit masks
 
 // internal stage bits (beyond the public HK_STAGE_*)
-constexpr unsigned kStageFeatureSort = 1u << 8;  // jax/util.py:186-197 row ordering
+constexpr unsigned kStageFeatureSort = 1u << 8;   // jax/util.py:186-197 row ordering (last coordinate primary)
+constexpr unsigned kStageFeatureSort0 = 1u << 9;  // core/tensor_points.py:72-74 (coordinate 0 alone, stable)
+constexpr unsigned kStageFeatureSorts = kStageFeatureSort | kStageFeatureSort0;
+
+// row orderings (descending) of the rank helpers
+enum KeyOrder : int {
+  kKeyLast = 0,   // lexicographic, last coordinate primary: the observation features' lexsort
+  kKeyFirst = 1,  // lexicographic, coordinate 0 primary: the list semantics (_list_ops.py:25-41)
+  kKeyCoord0 = 2  // coordinate 0 alone, ties in row order: TensorPoints.get_features
+};
 
 enum Mode : int { kModeStep = 0, kModeRollout = 1, kModeGenerate = 2, kModeZeillinger = 3 };
 // template-only variant of kModeRollout: the rollout that also writes per-step observations / records

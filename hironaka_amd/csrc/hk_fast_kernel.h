@@ -519,7 +519,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
       // their rank in the image, slots 0..n-1 become the game's live slots, registers re-gathered in that order
       np = run_stages<G::C, D>(q, nmax, c, axis, np, flags, stages & ~(unsigned)HK_STAGE_RESCALE);
       int rank[G::C];
-      feature_ranks<G::C, D, true>(q, nmax, rank);
+      feature_ranks<G::C, D, kKeyFirst>(q, nmax, rank);
       __syncthreads();
       scatter_ranked<G::C, D>(q, mine, rank, nmax);
       __syncthreads();
@@ -567,9 +567,10 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   // at their rank in descending key order: padding rows are all equal and end up behind them) -------
   __syncthreads();
   fill_image<M, D>(mine, pad);
-  if (MODE == kModeStepAux && (stages & kStageFeatureSort)) {
+  if (MODE == kModeStepAux && (stages & kStageFeatureSorts)) {
     int rank[G::C];
-    feature_ranks<G::C, D>(q, nmax, rank);
+    if (stages & kStageFeatureSort0) feature_ranks<G::C, D, kKeyCoord0>(q, nmax, rank);
+    else feature_ranks<G::C, D, kKeyLast>(q, nmax, rank);
     scatter_ranked<G::C, D>(q, mine, rank, nmax);
   } else {
     scatter_rows<M, G::C, D>(q, mine, gmask, nmax);
@@ -635,7 +636,7 @@ int launch_fast_t(Params prm, hipStream_t stream) {
   launch_prepare();
   const bool sorted_out = (prm.stages & HK_STAGE_NEWTON) &&
                           ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED));
-  if (prm.mode == kModeStep && (prm.class_out || (prm.stages & kStageFeatureSort) || sorted_out))
+  if (prm.mode == kModeStep && (prm.class_out || (prm.stages & kStageFeatureSorts) || sorted_out))
     hipLaunchKernelGGL((fast_kernel<M, D, kModeStepAux>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
                        prm.in_stride, prm.batch, prm.games_per_block, prm);
   else if (prm.mode == kModeStep)
@@ -668,7 +669,7 @@ inline bool fast_supported(const Params& prm, int dtype) {
                      (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER)))
     return false;
   if (prm.flags & (HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_TEAM)) return false;
-  if ((prm.stages & kStageFeatureSort) && prm.mode != kModeStep) return false;
+  if ((prm.stages & kStageFeatureSorts) && prm.mode != kModeStep) return false;
   if (prm.mode == kModeZeillinger) return false;
 #define HK_X(M_, D_) if (prm.m == M_ && prm.d == D_) return fast_aligned_t<M_, D_>(prm);
   HK_FAST_SPECS(HK_X)

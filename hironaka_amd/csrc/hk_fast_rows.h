@@ -350,14 +350,14 @@ __device__ __forceinline__ int run_stages(float (&q)[C * D], int nmax, const flo
 }
 
 // ---- observation features (jax/util.py:186-197): rows in descending order, LAST coordinate primary ------
-// a's key strictly greater than b's.  FIRST: coordinate 0 is the primary key (the descending-lexicographic
-// order of the list semantics, _list_ops.py:25-41); otherwise the last one (the features' lexsort).
-template <int D, bool FIRST = false>
+// a's key strictly greater than b's, in the order KEY (KeyOrder)
+template <int D, int KEY = kKeyLast>
 __device__ __forceinline__ bool key_gt(const float* a, const float* b) {
+  if (KEY == kKeyCoord0) return a[0] > b[0];
   bool gt = false, eq = true;
 #pragma unroll
   for (int kk = 0; kk < D; ++kk) {
-    const int k = FIRST ? kk : D - 1 - kk;
+    const int k = (KEY == kKeyFirst) ? kk : D - 1 - kk;
     gt |= eq && (a[k] > b[k]);
     eq &= (a[k] == b[k]);
   }
@@ -365,8 +365,8 @@ __device__ __forceinline__ bool key_gt(const float* a, const float* b) {
 }
 
 // rank[r] = position of live row r in the sorted order = number of live rows that come before it (greater
-// key; equal keys are equal rows, the lower index first).  Holes count for nothing.
-template <int C, int D, bool FIRST = false>
+// key; among equal keys the lower index first).  Holes count for nothing.
+template <int C, int D, int KEY = kKeyLast>
 __device__ __forceinline__ void feature_ranks(const float (&q)[C * D], int nmax, int (&rank)[C]) {
 #pragma unroll
   for (int r = 0; r < C; ++r) rank[r] = 0;
@@ -378,7 +378,7 @@ __device__ __forceinline__ void feature_ranks(const float (&q)[C * D], int nmax,
       constexpr int j = decltype(jc)::value;
       if (j >= nmax) return false;
       const bool live_j = q[j * D] < INFINITY;
-      const bool j_first = key_gt<D, FIRST>(&q[j * D], &q[i * D]);  // otherwise i (the lower index) comes first
+      const bool j_first = key_gt<D, KEY>(&q[j * D], &q[i * D]);  // otherwise i (the lower index) comes first
       rank[j] += (!j_first && live_i) ? 1 : 0;
       rank[i] += (j_first && live_j) ? 1 : 0;
       return true;

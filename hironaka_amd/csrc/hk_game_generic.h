@@ -287,13 +287,13 @@ __device__ inline int zeillinger_list_game(const T* p, int m, int d) {
 
 // stable in-place insertion sort, descending, LAST coordinate primary (lexsort(-x^T))
 template <typename T>
-__device__ inline void feature_sort_game(T* p, int m, int d, T* row) {
+__device__ inline void feature_sort_game(T* p, int m, int d, T* row, bool coord0) {
   for (int i = 1; i < m; ++i) {
     for (int k = 0; k < d; ++k) row[k] = p[i * d + k];
     int pos = i;
     while (pos > 0) {
-      bool before = false;
-      for (int k = d - 1; k >= 0; --k) {
+      bool before = coord0 && row[0] > p[(pos - 1) * d];
+      for (int k = d - 1; k >= 0 && !coord0; --k) {
         const T a = row[k], b = p[(pos - 1) * d + k];
         if (a > b) { before = true; break; }
         if (a < b) break;
@@ -318,7 +318,7 @@ __device__ inline void stages_game(T* p, int m, int d, T* c, int axis, T pad, un
       sort_compact_game(p, m, d, pad, c);
   }
   if (stages & HK_STAGE_RESCALE) rescale_game(p, m, d, pad, flags);
-  if (stages & kStageFeatureSort) feature_sort_game(p, m, d, c);
+  if (stages & kStageFeatureSorts) feature_sort_game(p, m, d, c, (stages & kStageFeatureSort0) != 0);
 }
 
 }  // namespace hk

@@ -342,10 +342,9 @@ __device__ __forceinline__ int team_zeillinger(const float (&q)[C * D], const fl
   return encode_mask((1u << lo) | (1u << hi));
 }
 
-// rank of each of the lane's rows among the team's live rows in descending key order (FIRST: coordinate 0
-// primary -- the list semantics' lexicographic order; otherwise the last -- the features' lexsort; equal
-// keys are equal rows, the lower index first).  The region must hold the mirror of the rows.
-template <int D, int C, bool FIRST>
+// rank of each of the lane's rows among the team's live rows in descending key order (KEY: a KeyOrder; among
+// equal keys the lower index first).  The region must hold the mirror of the rows.
+template <int D, int C, int KEY>
 __device__ __forceinline__ void team_ranks(const float (&q)[C * D], const float* mine, int tl, int nmax, int smax,
                                            int (&rank)[C]) {
 #pragma unroll
@@ -357,8 +356,8 @@ __device__ __forceinline__ void team_ranks(const float (&q)[C * D], const float*
     unrolled_while<0, C>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
       if (s >= smax) return false;
-      const bool j_greater = key_gt<D, FIRST>(pj, &q[s * D]);
-      const bool i_greater = key_gt<D, FIRST>(&q[s * D], pj);
+      const bool j_greater = key_gt<D, KEY>(pj, &q[s * D]);
+      const bool i_greater = key_gt<D, KEY>(&q[s * D], pj);
       const bool before = live_j && (j_greater || (!i_greater && j < kTeam * s + tl));
       rank[s] += before ? 1 : 0;
       return true;
@@ -383,12 +382,14 @@ __device__ __forceinline__ void team_scatter_ranked(const float (&q)[C * D], flo
   });
 }
 
-// observation features (jax/util.py:186-197): pad everywhere, the live rows at their rank
+// observation features (jax/util.py:186-197; coord0: core/tensor_points.py:72-74): pad everywhere, the live
+// rows at their rank
 template <int D, int C>
 __device__ __forceinline__ void team_publish_ranked(const float (&q)[C * D], float* mine, int m, float pad, int tl,
-                                                    int nmax, int smax, bool active) {
+                                                    int nmax, int smax, bool active, bool coord0) {
   int rank[C];
-  team_ranks<D, C, false>(q, mine, tl, nmax, smax, rank);
+  if (coord0) team_ranks<D, C, kKeyCoord0>(q, mine, tl, nmax, smax, rank);
+  else team_ranks<D, C, kKeyLast>(q, mine, tl, nmax, smax, rank);
   __syncthreads();
   float pv[D];
 #pragma unroll
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
         team_mirror<D, C>(q, mine, tl, smax);
         __syncthreads();
         int rank[C];
-        team_ranks<D, C, true>(q, mine, tl, nmax, smax, rank);
+        team_ranks<D, C, kKeyFirst>(q, mine, tl, nmax, smax, rank);
         __syncthreads();
         team_scatter_ranked<D, C>(q, mine, rank, smax);
         __syncthreads();
@@ -671,10 +672,10 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
 
   // ---- 5. publish ----------------------------------------------------------------------------------
   __syncthreads();
-  if (MODE == kModeStepAux && (stages & kStageFeatureSort)) {
+  if (MODE == kModeStepAux && (stages & kStageFeatureSorts)) {
     team_mirror<D, C>(q, mine, tl, smax);
     __syncthreads();
-    team_publish_ranked<D, C>(q, mine, m, pad, tl, nmax, smax, active);
+    team_publish_ranked<D, C>(q, mine, m, pad, tl, nmax, smax, active, (stages & kStageFeatureSort0) != 0);
   } else {
     team_publish<D, C>(q, orig, mine, m, pad, tl, smax, active);
   }
@@ -691,7 +692,7 @@ inline bool team_supported(const Params& prm, int dtype) {
       ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)))
     return false;
   if (prm.flags & HK_FLAG_FORCE_GENERIC) return false;
-  if ((prm.stages & kStageFeatureSort) && prm.mode != kModeStep) return false;
+  if ((prm.stages & kStageFeatureSorts) && prm.mode != kModeStep) return false;
   if (prm.mode == kModeZeillinger) return false;
   if (prm.d < 2 || prm.d > 6 || prm.m > kTeam * kTeamSlots) return false;
   return true;
@@ -724,7 +725,7 @@ template <int D>
 int launch_team_d(const Params& prm, hipStream_t stream) {
   const bool sorted_out = (prm.stages & HK_STAGE_NEWTON) &&
                           ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED));
-  if (prm.mode == kModeStep && (prm.class_out || (prm.stages & kStageFeatureSort) || sorted_out))
+  if (prm.mode == kModeStep && (prm.class_out || (prm.stages & kStageFeatureSorts) || sorted_out))
     return launch_team_t<D, kModeStepAux>(prm, stream);
   if (prm.mode == kModeStep) return launch_team_t<D, kModeStep>(prm, stream);
   if (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER)

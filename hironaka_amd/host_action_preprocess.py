@@ -99,3 +99,33 @@ def batch_encode_one_hot(multi_binary: torch.Tensor) -> torch.Tensor:
 
 def encode_one_hot(multi_binary: torch.Tensor) -> torch.Tensor:
     return batch_encode_one_hot(multi_binary.reshape(1, -1))[0]
+
+
+class HostActionEncoder:
+    """The torch trainers' codec object (src/_fn.py:241-325): ``encode`` / ``decode`` between a list of chosen
+    coordinates and the class id, ``encode_tensor`` / ``decode_tensor`` between [B, dim] 0/1 masks and [B]
+    class ids on device tensors (decode_tensor runs ``hk_decode_host_class``)."""
+
+    def __init__(self, dim: int = 3):
+        _check_dim(dim)
+        self.dim = dim
+        # the class ids' integers: 1 .. 2^dim - 1 without the powers of two (src/_fn.py:256-259)
+        self.action_translate = [v for v in range(1, 2 ** dim) if v & (v - 1)]
+
+    def encode(self, coords) -> int:
+        assert len(coords) > 1
+        v = sum(1 << int(c) for c in coords)
+        return v - (v.bit_length() - 1) - 2
+
+    def encode_tensor(self, coords: torch.Tensor) -> torch.Tensor:
+        assert coords.dim() == 2
+        return batch_encode(coords)
+
+    def decode(self, action: int):
+        assert 0 <= action < num_classes(self.dim)
+        v = self.action_translate[action]
+        return [k for k in range(self.dim) if (v >> k) & 1]
+
+    def decode_tensor(self, actions: torch.Tensor, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+        assert actions.dim() == 1
+        return ops.decode_host_class(actions, self.dim, dtype)

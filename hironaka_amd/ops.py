@@ -281,6 +281,21 @@ def get_features(points: torch.Tensor, scale_observation: bool = True, padding_v
     return out if orig == out.dtype else out.to(orig)
 
 
+def get_features_torch(points: torch.Tensor, padding_value: float = -1.0) -> torch.Tensor:
+    """TensorPoints.get_features (core/tensor_points.py:72-74): [B, m, d] rows ordered by coordinate 0,
+    descending (unavailable rows last); rows with equal coordinate 0 keep their order."""
+    pts, orig = _state(points)
+    if pts.dim() != 3:
+        raise ValueError(f"points must be [B, m, d]. Got {tuple(pts.shape)}.")
+    b, m, d = pts.shape
+    out = torch.empty_like(pts)
+    with torch.cuda.device(pts.device):
+        check(lib().hk_get_features_torch(pts.data_ptr(), m * d, out.data_ptr(), m * d, b, m, d,
+                                          _TORCH2HK[pts.dtype], float(padding_value), _stream(pts)),
+              "hk_get_features_torch")
+    return out if orig == out.dtype else out.to(orig)
+
+
 def generate_points(batch: int, max_points: int, dim: int, max_value: int, seed: int, *,
                     game_offset: int = 0, dtype=torch.float32, device=None, newton=True, reposition=True,
                     rescale=False, padding_value: float = -1.0, flags: int = 0,

@@ -34,6 +34,7 @@
  *                            jax/players.py:28-39,142-212 fixed policies fused in
  *   hk_zeillinger            jax/players.py:55-109 zeillinger_fn, host.py:54-95 Zeillinger
  *   hk_get_features          jax/util.py:172-214 get_feature_fn (order_and_rescale)
+ *   hk_get_features_torch    core/tensor_points.py:72-74 TensorPoints.get_features
  *   hk_decode_host_class     jax/host_action_preprocess.py:8-65, src/_fn.py:241-325
  */
 #ifndef HIRONAKA_HIP_H
@@ -274,6 +275,13 @@ int hk_zeillinger(const void* points, int64_t stride, int32_t* class_out, int ba
 int hk_get_features(const void* points_in, int64_t in_stride, void* features_out,
                     int64_t out_stride, int batch, int max_points, int dim, int dtype,
                     int scale_observation, double padding_value, void* stream);
+
+/* ---- the torch container's observation (core/tensor_points.py:72-74): rows ordered by coordinate 0,
+ * descending -- unavailable rows last -- values untouched.  The reference leaves the order among equal
+ * coordinates 0 to torch.argsort; here such rows keep their order (stable).                     */
+int hk_get_features_torch(const void* points_in, int64_t in_stride, void* features_out,
+                          int64_t out_stride, int batch, int max_points, int dim, int dtype,
+                          double padding_value, void* stream);
 
 /* ---- host action codec ------------------------------------------------------------------ */
 int hk_decode_host_class(const int32_t* class_in, void* mask_out, int mask_dtype, int batch,

@@ -187,6 +187,16 @@ def get_features(points: np.ndarray, scale_observation=True, padding_value=-1.0)
     return out
 
 
+def get_features_torch(points: np.ndarray, padding_value=-1.0) -> np.ndarray:
+    """TensorPoints.get_features (core/tensor_points.py:72-74), ties in row order; [B, m, d]"""
+    points = np.ascontiguousarray(points)
+    b, m, d = points.shape
+    out = np.empty((b, m, d), dtype=points.dtype)
+    _check(lib().hko_get_features_torch(_ptr(points), m * d, _ptr(out), m * d, b, m, d, _hk_dtype(points),
+                                        padding_value))
+    return out
+
+
 def generate_points(batch, max_points, dim, max_value, seed, game_offset=0, dtype=np.float32,
                     stages=A.HK_STAGE_NEWTON | A.HK_STAGE_REPOSITION, padding_value=-1.0, flags=0):
     out = np.empty((batch, max_points, dim), dtype=dtype)

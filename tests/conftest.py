@@ -28,5 +28,10 @@ def live_torch():
 
 
 @pytest.fixture(scope="session")
+def live_fused():
+    return np.load(os.path.join(GOLDEN, "live_fused_game.npz"))
+
+
+@pytest.fixture(scope="session")
 def live_list():
     return np.load(os.path.join(GOLDEN, "live_list.npz"))

@@ -12,7 +12,9 @@ package __init__ files that import jax:
     hironaka/core/points_base.py, list_points.py, tensor_points.py
     hironaka/points.py, host.py, agent.py, game.py, policy/policy.py
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+    hironaka/trainer/timer.py, fused_game.py   (live_fused_game.npz)
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [torch list fused]
 """
 import importlib.util
 import os
@@ -224,14 +226,94 @@ def make_list(ref, rng):
     return len(rec)
 
 
+class SetNet(torch.nn.Module):
+    """A row-permutation-invariant linear 'network' with exactly representable arithmetic (small integer
+    weights, distinct dyadic biases): logits = sum_i rows_i @ W (+ coords @ V) + bias.  The reference orders
+    rows with equal coordinate 0 however torch.argsort happens to; an invariant net makes the game's
+    trajectory independent of that.  tests/test_gpu_surfaces.py rebuilds the same module from the arrays."""
+
+    def __init__(self, w, bias, v=None):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.tensor(w, dtype=torch.float32), requires_grad=False)
+        self.bias = torch.nn.Parameter(torch.tensor(bias, dtype=torch.float32), requires_grad=False)
+        self.v = None if v is None else torch.nn.Parameter(torch.tensor(v, dtype=torch.float32), requires_grad=False)
+
+    def forward(self, x):
+        if isinstance(x, dict):
+            return x["points"].sum(dim=1) @ self.w + x["coords"] @ self.v + self.bias
+        return x.sum(dim=1) @ self.w + self.bias
+
+
+def make_fused_game(ref, rng):
+    """TensorPoints.get_features (tensor_points.py:72-74) on games whose live rows have distinct first
+    coordinates (the only inputs on which the reference's unstable argsort is defined), and
+    FusedGame.step (trainer/fused_game.py:54-102) for both roles with the SetNet players above,
+    exploration off, three consecutive steps per role."""
+    _pkg("hironaka.trainer")
+    _load("hironaka.trainer.timer", "hironaka/trainer/timer.py")
+    sys.modules["hironaka.src"].HostActionEncoder = ref.fn.HostActionEncoder
+    fg = _load("hironaka.trainer.fused_game", "hironaka/trainer/fused_game.py")
+    rec = {}
+    for (m, d) in [(5, 3), (20, 3), (8, 4), (12, 5)]:
+        tag = f"features_m{m}_d{d}"
+        b = 40
+        p = rng.integers(0, 50, (b, m, d)).astype(np.float32)
+        for g in range(b):
+            p[g, :, 0] = rng.permutation(60)[:m]  # distinct first coordinates
+        p[rng.random((b, m)) < 0.4] = -1.0
+        p[0] = -1.0
+        rec[tag + "/points"] = p
+        rec[tag + "/features"] = ref.TensorPoints(torch.tensor(p), padding_value=-1.0).get_features().numpy()
+    for (m, d) in [(20, 3), (8, 4)]:
+        n_cls = 2 ** d - d - 1
+        for role in ("host", "agent"):
+            for scale in (False,):
+                tag = f"fused_m{m}_d{d}_{role}"
+                b = 64
+                hw = rng.integers(-1, 2, (d, n_cls)).astype(np.float32)
+                hb = (np.arange(n_cls) / 64.0).astype(np.float32)
+                aw = rng.integers(-1, 2, (d, d)).astype(np.float32)
+                av = rng.integers(-1, 2, (d, d)).astype(np.float32)
+                ab = (np.arange(d)[::-1] / 64.0).astype(np.float32)
+                start = rng.integers(0, 5, (b, m, d)).astype(np.float32)
+                start[rng.random((b, m)) < 0.3] = -1.0
+                start[0] = -1.0
+                start[1, 1:] = -1.0
+                rec[tag + "/host_w"], rec[tag + "/host_b"] = hw, hb
+                rec[tag + "/agent_w"], rec[tag + "/agent_v"], rec[tag + "/agent_b"] = aw, av, ab
+                rec[tag + "/start"] = start
+                game = fg.FusedGame(SetNet(hw, hb), SetNet(aw, ab, av), device="cpu", log_time=False)
+                pts = ref.TensorPoints(torch.tensor(start), padding_value=-1.0)
+                pts.get_newton_polytope()
+                for t in range(3):
+                    obs, act, rew, done, nxt = game.step(pts, role, scale_observation=scale, exploration_rate=0.0)
+                    if role == "host":
+                        rec[tag + f"/t{t}_obs"], rec[tag + f"/t{t}_next"] = obs.numpy(), nxt.numpy()
+                    else:
+                        rec[tag + f"/t{t}_obs"], rec[tag + f"/t{t}_next"] = obs["points"].numpy(), nxt["points"].numpy()
+                        rec[tag + f"/t{t}_obs_coords"] = obs["coords"].numpy()
+                        rec[tag + f"/t{t}_next_coords"] = nxt["coords"].numpy()
+                    rec[tag + f"/t{t}_actions"] = act.numpy().astype(np.int64)
+                    rec[tag + f"/t{t}_rewards"] = rew.numpy()
+                    rec[tag + f"/t{t}_dones"] = done.numpy()
+                    rec[tag + f"/t{t}_state"] = pts.points.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "live_fused_game.npz"), **rec)
+    return len(rec)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit(f"{REF} not present: fixtures can only be regenerated next to the reference")
     ref = load_reference()
+    which = sys.argv[1:] or ["torch", "list", "fused"]
     rng = np.random.default_rng(20260101)
-    n1 = make_torch(ref, rng)
-    n2 = make_list(ref, rng)
-    print(f"wrote live_torch.npz ({n1} arrays), live_list.npz ({n2} arrays)")
+    if "torch" in which or "list" in which:  # these two share one stream of draws
+        n1 = make_torch(ref, rng)
+        n2 = make_list(ref, rng)
+        print(f"wrote live_torch.npz ({n1} arrays), live_list.npz ({n2} arrays)")
+    if "fused" in which:
+        n3 = make_fused_game(ref, np.random.default_rng(20260102))
+        print(f"wrote live_fused_game.npz ({n3} arrays)")
 
 
 if __name__ == "__main__":

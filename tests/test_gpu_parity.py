@@ -633,3 +633,28 @@ def test_zeillinger_operator_matches_oracle(spec):
     # records with a stride (agent observations) and a ragged batch
     rec = np.concatenate([g.reshape(b, m * d), np.ones((b, d), np.float32)], axis=1)[:333]
     assert np.array_equal(host(ops.zeillinger(dev(rec), spec=spec)), CO.zeillinger(g[:333], "jax"))
+
+
+@pytest.mark.parametrize("spec", [(20, 3), (5, 3), (8, 4), (20, 4), (7, 3), (33, 6), (50, 4), (9, 7)])
+def test_features_torch_matches_oracle(spec, live_fused):
+    """hk_get_features_torch (core/tensor_points.py:72-74) on the register-resident, team and generic kernels
+    against the C oracle -- ties in coordinate 0 (stable), empty games, irregular rows (exact path), f64 --
+    and against the reference's own outputs where a fixture has this shape"""
+    m, d = spec
+    rng = np.random.default_rng(5 * m + d)
+    b = 777
+    p = rand_state(rng, b, m, d, np.float32, -1.0, maxv=4, holes=0.4)
+    p[0] = -1.0
+    frac = np.where(p >= 0, p / np.float32(3.0), p).astype(np.float32)
+    r = p.copy()
+    if m >= 3:
+        r[7, 1] = -3.0
+        r[8, 0, 0] = -0.5
+    for states in (p, frac, r, p.astype(np.float64)):
+        want = CO.get_features_torch(states)
+        got = host(ops.get_features_torch(torch.as_tensor(states).cuda()))
+        assert np.array_equal(got, want) and got.dtype == want.dtype
+    tag = f"features_m{m}_d{d}"
+    if f"{tag}/points" in live_fused.files:
+        got = host(ops.get_features_torch(torch.as_tensor(live_fused[f"{tag}/points"]).cuda()))
+        assert np.array_equal(got, live_fused[f"{tag}/features"])

@@ -8,14 +8,16 @@ import torch
 
 from hironaka_amd import _abi as A
 from hironaka_amd import ops
-from hironaka_amd.agent import ChooseFirstAgent, RandomAgent
+from hironaka_amd.agent import Agent, ChooseFirstAgent, RandomAgent
 from hironaka_amd.core import HipPoints
+from hironaka_amd.fused_game import FusedGame
+from hironaka_amd.game import GameHironaka
 from hironaka_amd.functional import (flatten, generate_pts, get_done_from_flatten, get_dones, get_feature_fn,
                                      get_preprocess_fns, get_reward_fn, get_take_actions, make_agent_obs)
 from hironaka_amd.gym_env import HironakaAgentEnv, HironakaHostEnv
 from hironaka_amd.host import AllCoordHost, RandomHost, Zeillinger
-from hironaka_amd.host_action_preprocess import (batch_encode, batch_encode_one_hot, decode_table, get_batch_decode,
-                                                 get_batch_decode_from_one_hot)
+from hironaka_amd.host_action_preprocess import (HostActionEncoder, batch_encode, batch_encode_one_hot, decode_table,
+                                                 get_batch_decode, get_batch_decode_from_one_hot)
 from hironaka_amd.players import (all_coord_host_fn, choose_first_agent_fn, choose_last_agent_fn,
                                   get_host_with_flattened_obs, random_agent_fn, random_host_fn, zeillinger_fn,
                                   zeillinger_fn_slice)
@@ -428,3 +430,135 @@ def test_select_sample_after_sim():
         assert bool((mixed | ~undone).all()) and n <= int(mixed.sum()) <= 2 * n
         assert torch.equal(mixed, select_sample_after_sim(role, (obs, policy, value), 3, key=9))
         assert 0 < n < b * T
+
+
+# ---- src/_fn.py:241-325, game.py:84-119, trainer/fused_game.py:54-163 ---------------------------------
+
+def test_host_action_encoder(live_torch):
+    """test/testUtil.py:226-236 + the reference's own tables"""
+    enc = HostActionEncoder(3)
+    assert [enc.decode(i) for i in range(4)] == [[0, 1], [0, 2], [1, 2], [0, 1, 2]]
+    for d in range(2, 8):
+        enc = HostActionEncoder(d)
+        n = 2 ** d - d - 1
+        ids = torch.arange(n, dtype=torch.int32).cuda()
+        table = enc.decode_tensor(ids)
+        assert table.dtype == torch.float32 and np.array_equal(host(table), live_torch[f"codec/d{d}"])
+        assert np.array_equal(host(enc.encode_tensor(table)), live_torch[f"codec/d{d}_roundtrip"])
+        for i in range(n):
+            coords = enc.decode(i)
+            assert enc.encode(coords) == i and host(table[i]).nonzero()[0].tolist() == coords
+
+
+class _ReplayAgent(Agent):
+    """plays the axes the reference's RandomAgent drew when the fixture was recorded"""
+
+    def __init__(self, axes):
+        self.axes, self.t = axes, 0
+
+    def _get_actions(self, points, coords):
+        self.t += 1
+        return torch.as_tensor(self.axes[self.t - 1]).to(points.device)
+
+
+@pytest.mark.parametrize("scale", [0, 1])
+def test_game_hironaka_replays_reference_game(live_list, scale):
+    """BASELINE config 1 (dim 3, 10 points, 32 games, Zeillinger vs the recorded agent): GameHironaka over a
+    list-semantics HipPoints reproduces the reference's game -- every state, every host choice, the stop"""
+    g = lambda k: live_list[f"game_scale{scale}/{k}"]
+    states, masks, axes = g("states"), g("masks"), g("axes")
+    pts = HipPoints(torch.as_tensor(g("start")), dtype=torch.float64, semantics="list", value_threshold=1e8)
+    game = GameHironaka(pts, Zeillinger(), _ReplayAgent(axes), scale_observation=bool(scale))
+    assert np.array_equal(host(game.state.points), states[0]) and not game.stopped
+    for t in range(len(masks)):
+        went_on = game.step()
+        assert np.array_equal(host(game.coord_history[-1]), masks[t]), t
+        assert np.array_equal(host(game.move_history[-1]), axes[t]), t
+        assert np.array_equal(host(game.state.points), states[t + 1]), t
+        assert went_on == (t + 1 < len(masks))
+    assert game.stopped and game.state.ended and not game.step()
+    assert len(game.coord_history) == len(masks)
+
+
+class _SetNet(torch.nn.Module):
+    """the players of tests/golden/make_golden.py::make_fused_game, rebuilt from the committed arrays"""
+
+    def __init__(self, w, bias, v=None):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.tensor(w), requires_grad=False)
+        self.bias = torch.nn.Parameter(torch.tensor(bias), requires_grad=False)
+        self.v = None if v is None else torch.nn.Parameter(torch.tensor(v), requires_grad=False)
+
+    def forward(self, x):
+        if isinstance(x, dict):
+            return x["points"].sum(dim=1) @ self.w + x["coords"] @ self.v + self.bias
+        return x.sum(dim=1) @ self.w + self.bias
+
+
+def _canonical(rows):
+    """[n, m, d]: every game's rows in one canonical order (the reference leaves ties in coordinate 0 open)"""
+    out = np.empty_like(rows)
+    for i, g in enumerate(rows):
+        out[i] = g[np.lexsort(g.T)[::-1]]
+    return out
+
+
+@pytest.mark.parametrize("role", ["host", "agent"])
+@pytest.mark.parametrize("spec", [(20, 3), (8, 4)])
+def test_fused_game_step_matches_reference(live_fused, spec, role):
+    """FusedGame.step for three moves == the reference's FusedGame over TensorPoints with the same players:
+    experiences of the unfinished games (observations up to the order of rows with equal coordinate 0),
+    actions, rewards, dones and the state itself"""
+    m, d = spec
+    tag = f"fused_m{m}_d{d}_{role}"
+    g = lambda k: live_fused[f"{tag}/{k}"]
+    game = FusedGame(_SetNet(g("host_w"), g("host_b")), _SetNet(g("agent_w"), g("agent_b"), g("agent_v")),
+                     log_time=True)
+    pts = HipPoints(torch.as_tensor(g("start")))
+    pts.get_newton_polytope()
+    for t in range(3):
+        obs, act, rew, done, nxt = game.step(pts, role, scale_observation=False, exploration_rate=0.0)
+        o, n = (obs, nxt) if role == "host" else (obs["points"], nxt["points"])
+        assert np.array_equal(_canonical(host(o)), _canonical(g(f"t{t}_obs"))), t
+        assert np.array_equal(_canonical(host(n)), _canonical(g(f"t{t}_next"))), t
+        assert bool((o[:, :-1, 0] >= o[:, 1:, 0]).all())
+        if role == "agent":
+            assert np.array_equal(host(obs["coords"]), g(f"t{t}_obs_coords")), t
+            assert np.array_equal(host(nxt["coords"]), g(f"t{t}_next_coords")), t
+        assert act.shape == (o.shape[0], 1) and np.array_equal(host(act), g(f"t{t}_actions")), t
+        assert rew.dtype == torch.float32 and np.array_equal(host(rew), g(f"t{t}_rewards")), t
+        assert done.dtype == torch.bool and np.array_equal(host(done), g(f"t{t}_dones")), t
+        assert np.array_equal(host(pts.points), g(f"t{t}_state")), t
+    assert "step-agent_move" in game.time_log
+    with pytest.raises(TypeError):
+        FusedGame(torch.nn.Identity(), torch.nn.Identity(), device="cpu")
+
+
+def test_fused_game_types_and_exploration():
+    """test/testTrainer.py:105-118: dtypes of the experiences for an f64 game; exploring players stay legal"""
+    m, d, b = 20, 3, 256
+    flat = torch.nn.Flatten()
+
+    class AgentNet(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(m * d + d, d)
+
+        def forward(self, x):
+            return self.lin(torch.cat([flat(x["points"]), x["coords"]], dim=1))
+
+    torch.manual_seed(0)
+    game = FusedGame(torch.nn.Sequential(flat, torch.nn.Linear(m * d, 4)), AgentNet(), dtype=torch.float64,
+                     log_time=False)
+    pts = HipPoints(torch.randint(5, (b, m, d)), dtype=torch.float64)
+    pts.get_newton_polytope()
+    before = host(pts.get_num_points())
+    exp = game.step(pts, "host", scale_observation=False)
+    assert exp[0].dtype == torch.float64 and exp[1].dtype == torch.int32 and exp[2].dtype == torch.float32
+    assert exp[3].dtype == torch.bool and exp[4].dtype == torch.float64
+    assert exp[0].shape == (int((before >= 2).sum()), m, d)
+    obs, act, rew, done, nxt = game.step(pts, "agent", scale_observation=True, exploration_rate=1.0)
+    assert obs["coords"].shape[1] == d and float(nxt["points"].max()) <= 1.0
+    chosen = torch.gather(obs["coords"], 1, act.long())
+    assert act.shape[1] == 1 and chosen.shape == act.shape
+    assert np.array_equal(host(rew), -host(done).astype(np.float32))

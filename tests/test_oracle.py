@@ -212,6 +212,21 @@ def test_live_torch_operators(O, live_torch):
         assert np.array_equal(O.rescale(un, pad, "torch"), g("game_scaled")), tag
 
 
+def test_live_torch_features(live_fused):
+    """TensorPoints.get_features as run by the reference (distinct first coordinates: the inputs on which its
+    unstable argsort is defined) == the restatement; plus the restatement's own tie rule (row order)"""
+    from oracle import c_oracle as CO
+    tags = sorted({k.split("/")[0] for k in live_fused.files if k.startswith("features_")})
+    assert len(tags) == 4
+    for tag in tags:
+        p = live_fused[f"{tag}/points"]
+        assert np.array_equal(CO.get_features_torch(p), live_fused[f"{tag}/features"]), tag
+        assert np.array_equal(CO.get_features_torch(p.astype(np.float64)), live_fused[f"{tag}/features"]), tag
+    p = np.array([[[1, 7], [2, 0], [-1, -1], [1, 3], [2, 5], [0, 9]]], dtype=np.float32)
+    want = np.array([[[2, 0], [2, 5], [1, 7], [1, 3], [0, 9], [-1, -1]]], dtype=np.float32)
+    assert np.array_equal(CO.get_features_torch(p), want)
+
+
 def test_live_torch_jax_agreement(O, live_torch):
     """On legal moves of unfinished games with padding -1 the JAX semantics must give the
     torch sibling's values."""
