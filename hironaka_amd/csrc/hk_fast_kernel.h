@@ -460,8 +460,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   gather_rows<M, G::C, D>(q, mine, gmask, nmax);
   if (MODE == kModeStepAux && prm.class_out) {  // hk_zeillinger: the class is the only output
     if (active)
-      prm.class_out[g] = ((flags & HK_SEM_MASK) == HK_SEM_LIST) ? c_zeillinger<G::C, D, true>(q, nmax)
-                                                                : c_zeillinger<G::C, D>(q, nmax);
+      prm.class_out[g] = c_zeillinger<G::C, D, true>(q, nmax, (flags & HK_SEM_MASK) == HK_SEM_LIST);
     return;
   }
   if (!active) np = 2;  // never "done", never counted
@@ -569,8 +568,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   fill_image<M, D>(mine, pad);
   if (MODE == kModeStepAux && (stages & kStageFeatureSorts)) {
     int rank[G::C];
-    if (stages & kStageFeatureSort0) feature_ranks<G::C, D, kKeyCoord0>(q, nmax, rank);
-    else feature_ranks<G::C, D, kKeyLast>(q, nmax, rank);
+    feature_ranks<G::C, D, kKeyLast>(q, nmax, rank, (stages & kStageFeatureSort0) != 0);
     scatter_ranked<G::C, D>(q, mine, rank, nmax);
   } else {
     scatter_rows<M, G::C, D>(q, mine, gmask, nmax);

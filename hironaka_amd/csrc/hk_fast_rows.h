@@ -350,9 +350,11 @@ __device__ __forceinline__ int run_stages(float (&q)[C * D], int nmax, const flo
 }
 
 // ---- observation features (jax/util.py:186-197): rows in descending order, LAST coordinate primary ------
-// a's key strictly greater than b's, in the order KEY (KeyOrder)
+// a's key strictly greater than b's, in the order KEY (KeyOrder); `coord0` (wave-uniform, looked at under
+// kKeyLast only) switches that instance to coordinate 0 alone at run time: the register-resident kernel
+// serves both feature orders with ONE copy of its unrolled pair loop (two copies spill)
 template <int D, int KEY = kKeyLast>
-__device__ __forceinline__ bool key_gt(const float* a, const float* b) {
+__device__ __forceinline__ bool key_gt(const float* a, const float* b, bool coord0 = false) {
   if (KEY == kKeyCoord0) return a[0] > b[0];
   bool gt = false, eq = true;
 #pragma unroll
@@ -361,13 +363,13 @@ __device__ __forceinline__ bool key_gt(const float* a, const float* b) {
     gt |= eq && (a[k] > b[k]);
     eq &= (a[k] == b[k]);
   }
-  return gt;
+  return (KEY == kKeyLast && coord0) ? (a[0] > b[0]) : gt;
 }
 
 // rank[r] = position of live row r in the sorted order = number of live rows that come before it (greater
 // key; among equal keys the lower index first).  Holes count for nothing.
 template <int C, int D, int KEY = kKeyLast>
-__device__ __forceinline__ void feature_ranks(const float (&q)[C * D], int nmax, int (&rank)[C]) {
+__device__ __forceinline__ void feature_ranks(const float (&q)[C * D], int nmax, int (&rank)[C], bool coord0 = false) {
 #pragma unroll
   for (int r = 0; r < C; ++r) rank[r] = 0;
   unrolled_while<0, C - 1>([&](auto ic) {
@@ -378,7 +380,7 @@ __device__ __forceinline__ void feature_ranks(const float (&q)[C * D], int nmax,
       constexpr int j = decltype(jc)::value;
       if (j >= nmax) return false;
       const bool live_j = q[j * D] < INFINITY;
-      const bool j_first = key_gt<D, KEY>(&q[j * D], &q[i * D]);  // otherwise i (the lower index) comes first
+      const bool j_first = key_gt<D, KEY>(&q[j * D], &q[i * D], coord0);  // otherwise i (the lower index) comes first
       rank[j] += (!j_first && live_i) ? 1 : 0;
       rank[i] += (j_first && live_j) ? 1 : 0;
       return true;
@@ -410,9 +412,11 @@ __device__ __forceinline__ void scatter_ranked(const float (&q)[C * D], float* m
 // subset is {argmin, argmax} of that difference; no valid pair -> class 0 (players.py:96-109).
 // LIST: Zeillinger._select_coord (host.py:70-95) instead -- every pair of available rows counts (no isclose
 // filter), the rows are in the state's physical order (which the gather keeps), a game with fewer than two
-// rows gives -1 and coinciding argmin / argmax the subset {0, 1}.
-template <int C, int D, bool LIST = false>
-__device__ __forceinline__ int c_zeillinger(const float (&q)[C * D], int nmax) {
+// rows gives -1 and coinciding argmin / argmax the subset {0, 1}.  BOTH: the variant is the wave-uniform
+// runtime flag `list` (hk_zeillinger's kernels: one copy of the pair loop for the two variants).
+template <int C, int D, bool BOTH = false>
+__device__ __forceinline__ int c_zeillinger(const float (&q)[C * D], int nmax, bool list_rt = false) {
+  const bool LIST = BOTH && list_rt;
   float bestL = INFINITY, bestS = INFINITY;
   float bd[D];
 #pragma unroll

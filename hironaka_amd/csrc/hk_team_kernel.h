@@ -268,9 +268,11 @@ __device__ __forceinline__ void team_publish(const float (&q)[C * D], const uint
 // i*64 + j makes "first minimum in row-major order" independent of the order in which the lanes visit the
 // pairs -- and two DPP exchanges leave the team's best pair, with its difference vector, in every lane.
 // The region must hold the mirror of the team's rows.
-// LIST: the list variant (see c_zeillinger)
-template <int D, int C, bool LIST = false>
-__device__ __forceinline__ int team_zeillinger(const float (&q)[C * D], const float* mine, int tl, int nmax, int smax) {
+// BOTH: jax or list variant by the runtime flag (see c_zeillinger)
+template <int D, int C, bool BOTH = false>
+__device__ __forceinline__ int team_zeillinger(const float (&q)[C * D], const float* mine, int tl, int nmax, int smax,
+                                               bool list_rt = false) {
+  const bool LIST = BOTH && list_rt;
   float bestL = INFINITY, bestS = INFINITY;
   int bestP = 0x7FFFFFFF;
   float bd[D];
@@ -388,8 +390,8 @@ template <int D, int C>
 __device__ __forceinline__ void team_publish_ranked(const float (&q)[C * D], float* mine, int m, float pad, int tl,
                                                     int nmax, int smax, bool active, bool coord0) {
   int rank[C];
-  if (coord0) team_ranks<D, C, kKeyCoord0>(q, mine, tl, nmax, smax, rank);
-  else team_ranks<D, C, kKeyLast>(q, mine, tl, nmax, smax, rank);
+  if (coord0) team_ranks<D, C, kKeyCoord0>(q, mine, tl, nmax, smax, rank);  // (a rolled loop over the mirror: two
+  else team_ranks<D, C, kKeyLast>(q, mine, tl, nmax, smax, rank);           //  copies are cheap here)
   __syncthreads();
   float pv[D];
 #pragma unroll
@@ -556,8 +558,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
     __syncthreads();
     team_mirror<D, C>(q, mine, tl, smax);
     __syncthreads();
-    const int zc = ((flags & HK_SEM_MASK) == HK_SEM_LIST) ? team_zeillinger<D, C, true>(q, mine, tl, nmax, smax)
-                                                          : team_zeillinger<D, C>(q, mine, tl, nmax, smax);
+    const int zc = team_zeillinger<D, C, true>(q, mine, tl, nmax, smax, (flags & HK_SEM_MASK) == HK_SEM_LIST);
     if (leader) prm.class_out[g] = zc;
     return;
   }

@@ -47,4 +47,5 @@ def main():
             t = timeit(f, iters=10)
             print(f"rollout T={T:2d} {kind} {t:8.2f} us  ({t/T:.2f} us/step)")
 
-main()
+if __name__ == "__main__":
+    main()
