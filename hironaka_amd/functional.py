@@ -122,6 +122,16 @@ def get_reward_fn(role: str) -> Callable:
     return reward_fn
 
 
+def get_value_est_fn(role: str) -> Callable:
+    """jax/util.py:153-169 -- the value of an unfinished game: +-1 / max(number of remaining points, 1)"""
+    sign = 1 if role == "host" else -1
+
+    def est_fn(last_values: torch.Tensor, num_points: torch.Tensor) -> torch.Tensor:
+        return 1 / torch.clamp(num_points, min=1) * sign
+
+    return est_fn
+
+
 @functools.lru_cache()
 def get_feature_fn(role: str, spec: Tuple[int, int], scale_observation: bool = True) -> Callable:
     """jax/util.py:172-214 -- [rescale] + rows ordered descending (last coordinate primary); the
@@ -190,3 +200,55 @@ def get_dynamic_policy_fn(spec: Tuple[int, int], host_fn: Callable, agent_fn: Ca
         return torch.nn.functional.pad(policy, (0, extra_action_dim), value=float("-inf")), value
 
     return dynamic_policy_fn
+
+
+def _name_of(obj):
+    if hasattr(obj, "__name__"):
+        return obj.__name__
+    if hasattr(obj, "func"):  # functools.partial
+        return _name_of(obj.func)
+    return None
+
+
+def apply_agent_action_mask(agent_policy: Callable, dimension: int, nan_free: bool = False) -> Callable:
+    """jax/util.py:287-305 -- restrict an agent's (policy, value) function to the host's subset, read from the
+    last `dimension` entries of the flattened observation (cut at 0.5).
+
+    The reference computes ``policy * mask - inf * (~mask)``; ``inf * 0`` is NaN, so with that expression the
+    ALLOWED entries come out NaN and the excluded ones -inf (an argmax then lands on the first allowed axis).
+    The default reproduces the expression as written; ``nan_free=True`` keeps the allowed logits instead."""
+
+    def masked_agent_policy(x: torch.Tensor, *args, **kwargs):
+        mask = x[..., x.shape[-1] - dimension:] > 0.5
+        policy_prior, value_prior = agent_policy(x, *args, **kwargs)
+        if nan_free:
+            return torch.where(mask, policy_prior, torch.full_like(policy_prior, float("-inf"))), value_prior
+        return policy_prior * mask - float("inf") * (~mask).to(policy_prior.dtype), value_prior
+
+    masked_agent_policy.__name__ = _name_of(agent_policy)
+    return masked_agent_policy
+
+
+def action_wrapper(policy_value_fn: Callable, dimension: Optional[int] = None) -> Callable:
+    """jax/util.py:308-327 -- (policy, value) function -> one-hot argmax actions, behind the agent's action mask
+    if `dimension` is given"""
+    masked_action = policy_value_fn if dimension is None else apply_agent_action_mask(policy_value_fn, dimension)
+
+    def wrapped_action_fn(x: torch.Tensor, *args, **kwargs) -> torch.Tensor:
+        out, _ = masked_action(x, *args, **kwargs)
+        return torch.nn.functional.one_hot(torch.argmax(out, dim=-1), out.shape[-1]).to(torch.float32)
+
+    wrapped_action_fn.__name__ = _name_of(policy_value_fn)
+    return wrapped_action_fn
+
+
+def mcts_wrapper(eval_loop: Callable) -> Callable:
+    """jax/util.py:330-341 -- an evaluation loop (simulation_fn.get_evaluation_loop) as a (policy, value)
+    function: log of the search's action weights (clipped at 1e-8, jax/loss.py:27-28) and the root values"""
+
+    def mcts_wrapped_policy(x: torch.Tensor, params, opp_params, key):
+        policy_output = eval_loop(key, x, (params,), (opp_params,))
+        return (torch.log(torch.clamp(policy_output.action_weights, min=1e-8)),
+                policy_output.search_tree.node_values[:, 0])
+
+    return mcts_wrapped_policy

@@ -73,6 +73,16 @@ def get_batch_decode_from_one_hot(dimension: int) -> Callable:
     return batch_decode_from_one_hot
 
 
+def decode_from_one_hot(one_hot: torch.Tensor, lookup_dict: torch.Tensor) -> torch.Tensor:
+    """one one-hot class vector -> its multi-binary mask, through a decode table (host_action_preprocess.py:38-45)"""
+    return lookup_dict[torch.argmax(one_hot)]
+
+
+def decode(cls: int, lookup_dict: torch.Tensor) -> torch.Tensor:
+    """one class id -> its multi-binary mask (host_action_preprocess.py:48-52)"""
+    return lookup_dict[cls]
+
+
 def batch_encode(multi_binary: torch.Tensor) -> torch.Tensor:
     """masks [B, dim] -> class ids: v - floor(log2 v) - 2 with v = sum 2^j m_j
     (host_action_preprocess.py:78-87, src/_fn.py:282-292)."""

@@ -98,6 +98,29 @@ def choose_first_agent_fn(pts: torch.Tensor, spec: Tuple[int, int], dtype=torch.
     return torch.nn.functional.one_hot(torch.argmax(host_action, dim=1), d).to(dtype)
 
 
+def choose_first_agent_fn_slice(pts: torch.Tensor, spec: Tuple[int, int]) -> torch.Tensor:
+    """players.py:156-170 -- one observation without batch axis"""
+    return choose_first_agent_fn(pts.unsqueeze(0), spec)[0]
+
+
+def choose_last_agent_fn_slice(pts: torch.Tensor, spec: Tuple[int, int]) -> torch.Tensor:
+    """players.py:185-199 -- one observation without batch axis"""
+    return choose_last_agent_fn(pts.unsqueeze(0), spec)[0]
+
+
+def char_vector(v1: torch.Tensor, v2: torch.Tensor) -> torch.Tensor:
+    """players.py:55-77 -- Zeillinger's characteristic vector (L, S) of a pair of points: L = max - min of
+    v1 - v2, S = #max + #min; a pair with a negative entry (an unavailable point) or with max ~ min gets
+    (inf, inf).  (hk_zeillinger computes the same thing over all pairs in registers.)"""
+    diff = v1 - v2
+    mx, mn = diff.max(), diff.min()
+    bad = bool((v1 < 0).any() | (v2 < 0).any() | torch.isclose(mx, mn))
+    if bad:
+        return torch.full((2,), float("inf"), dtype=diff.dtype, device=diff.device)
+    s = (diff == mx).sum() + (diff == mn).sum()
+    return torch.stack([mx - mn, s.to(diff.dtype)])
+
+
 def choose_last_agent_fn(pts: torch.Tensor, spec: Tuple[int, int], dtype=torch.float32, **kwargs) -> torch.Tensor:
     """players.py:186-212 -- highest coordinate of the host's subset."""
     m, d = spec

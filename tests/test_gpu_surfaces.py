@@ -562,3 +562,46 @@ def test_fused_game_types_and_exploration():
     chosen = torch.gather(obs["coords"], 1, act.long())
     assert act.shape[1] == 1 and chosen.shape == act.shape
     assert np.array_equal(host(rew), -host(done).astype(np.float32))
+
+
+def test_policy_wrappers():
+    """jax/util.py:153-169, 287-341; players.py:55-77,156-199; host_action_preprocess.py:38-52"""
+    from hironaka_amd.functional import action_wrapper, apply_agent_action_mask, get_value_est_fn, mcts_wrapper
+    from hironaka_amd.host_action_preprocess import decode, decode_from_one_hot
+    from hironaka_amd.players import char_vector, choose_first_agent_fn_slice, choose_last_agent_fn_slice
+    m, d = 4, 3
+    obs = torch.zeros(5, m * d + d).cuda()
+    obs[:, -d:] = dev([[1, 1, 0], [0, 1, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]])
+
+    def agent_policy(x, scale=1.0):
+        return scale * torch.arange(1, d + 1, device=x.device, dtype=torch.float32).expand(x.shape[0], d), torch.ones(x.shape[0])
+
+    masked = apply_agent_action_mask(agent_policy, d, nan_free=True)
+    pol, val = masked(obs, scale=2.0)
+    assert host(pol).tolist()[0] == [2.0, 4.0, -np.inf] and host(pol).tolist()[1] == [-np.inf, 4.0, 6.0]
+    literal, _ = apply_agent_action_mask(agent_policy, d)(obs)  # the reference's expression: inf * 0
+    assert np.isnan(host(literal)[0, :2]).all() and host(literal)[0, 2] == -np.inf
+    assert masked.__name__ == "agent_policy"
+    act = action_wrapper(agent_policy, d)(obs)
+    assert host(act).argmax(1).tolist() == [0, 1, 0, 0, 1]  # NaN wins the argmax: the first allowed axis
+    assert host(action_wrapper(agent_policy)(obs)).argmax(1).tolist() == [2] * 5
+    est = get_value_est_fn("agent")(None, torch.tensor([0, 1, 4]).cuda())
+    assert host(est).tolist() == [-1.0, -1.0, -0.25]
+    assert host(get_value_est_fn("host")(None, torch.tensor([2]).cuda())).tolist() == [0.5]
+    assert host(choose_first_agent_fn_slice(obs[1], (m, d))).tolist() == [0, 1, 0]
+    assert host(choose_last_agent_fn_slice(obs[0], (m, d))).tolist() == [0, 1, 0]
+    assert host(char_vector(dev([5, 0, 0]), dev([0, 0, 3]))).tolist() == [8.0, 2.0]  # test/testZeillinger.py:19
+    assert np.isinf(host(char_vector(dev([1, 1, 1]), dev([0, 0, 0])))).all()
+    assert np.isinf(host(char_vector(dev([-1, -1, -1]), dev([0, 2, 0])))).all()
+    table = decode_table(3)
+    assert host(decode(2, table)).tolist() == [0, 1, 1]
+    assert host(decode_from_one_hot(dev([0, 0, 1, 0]), table)).tolist() == [0, 1, 1]
+
+    class _Out:
+        action_weights = dev([[0.5, 0.5, 0.0]])
+
+        class search_tree:
+            node_values = dev([[0.25, 9.0]])
+
+    pol, val = mcts_wrapper(lambda key, x, p, o: _Out)(None, None, None, 0)
+    assert np.allclose(host(pol), np.log([[0.5, 0.5, 1e-8]])) and host(val).tolist() == [0.25]
