@@ -116,8 +116,8 @@ def cpu_baseline(seconds: float = 12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)
-    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=200000)
+    ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--batch", type=int, default=BATCH, help="games per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-step", action="store_true")
