@@ -58,3 +58,19 @@ class ChooseFirstAgent(Agent):
 
     def _get_actions(self, points, coords):
         return torch.argmax((coords > 0).to(torch.int32), dim=1).to(torch.int32)
+
+
+class PolicyAgent(Agent):
+    """agent.py:101-111 -- an agent that asks a policy object: ``policy.predict((features, coords))`` returns
+    one axis per game."""
+
+    def __init__(self, policy, **kwargs):
+        self._policy = policy
+
+    def move(self, points, coords: torch.Tensor, inplace: bool = True, sem: str = "list") -> torch.Tensor:
+        self._features = points.get_features() if hasattr(points, "get_features") else None
+        return super().move(points, coords, inplace, sem)
+
+    def _get_actions(self, points, coords):
+        features = points if self._features is None else self._features
+        return torch.as_tensor(self._policy.predict((features, coords)), device=points.device).to(torch.int32)

@@ -59,7 +59,8 @@ int launch_generic(Params& prm, int dtype, hipStream_t stream) {
 }
 
 // kernel selection: register-resident specialisation -> team kernel (f32, dim 2..6, <= 64 rows; also the
-// specialised shapes on HK_FLAG_FORCE_TEAM) -> generic kernel (anything else: f64, list semantics, sorted output, Zeillinger, feature sort)
+// specialised shapes on HK_FLAG_FORCE_TEAM) -> generic kernel (anything else: f64, dim > 6, > 64 rows,
+// HK_FLAG_FORCE_GENERIC, and the few mode / semantics combinations fast_supported / team_supported decline)
 int launch(Params& prm, int dtype, hipStream_t stream) {
   if (prm.batch == 0) return HK_OK;
   if (fast_supported(prm, dtype)) return launch_fast(prm, stream);

@@ -42,17 +42,17 @@ class Game(abc.ABC):
         """one move of every game; True if the games go on, False if they had stopped or stop now"""
 
     def _show(self, coords, action, weights, ended):
-        self.logger.info(f"Host move: {coords}")
-        self.logger.info(f"Agent move: {action}")
+        lines = [f"Host move: {coords}", f"Agent move: {action}"]
         if weights is not None:
-            self.logger.info(f"Weights: {weights}")
-        self.logger.info(f"Game Ended: {ended}")
+            lines.append(f"Weights: {weights}")
+        for line in lines + [f"Game Ended: {ended}"]:
+            self.logger.info(line)
 
     def print_history(self):
-        self.logger.info("Coordinate history (host choices):")
-        self.logger.info(self.coord_history)
-        self.logger.info("Move history (agent choices):")
-        self.logger.info(self.move_history)
+        for title, history in (("Coordinate history (host choices):", self.coord_history),
+                               ("Move history (agent choices):", self.move_history)):
+            self.logger.info(title)
+            self.logger.info(history)
 
 
 class GameHironaka(Game):

@@ -73,3 +73,20 @@ class Zeillinger(Host):
         cls = ops.zeillinger(points, sem="list")
         mask = ops.decode_host_class(cls.clamp(min=0), d, torch.int32)
         return mask * (cls >= 0).unsqueeze(1).to(torch.int32)
+
+
+class PolicyHost(Host):
+    """host.py:98-113 -- a host that asks a policy object: ``policy.predict(features)`` on the container's
+    features (``get_features()``) returns the multi-binary subsets [B, d]."""
+
+    def __init__(self, policy, use_discrete_actions_for_host: Optional[bool] = False, **kwargs):
+        self._policy = policy
+        self.use_discrete_actions_for_host = kwargs.get("use_discrete_actions_for_host", use_discrete_actions_for_host)
+
+    def select_coord(self, points, debug=False) -> torch.Tensor:
+        self._features = points.get_features() if hasattr(points, "get_features") else _as_points(points)
+        return super().select_coord(points, debug)
+
+    def _select_coord(self, points: torch.Tensor) -> torch.Tensor:
+        coords = torch.as_tensor(self._policy.predict(self._features), device=points.device)
+        return (coords == 1).to(torch.int32)

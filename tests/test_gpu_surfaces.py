@@ -605,3 +605,29 @@ def test_policy_wrappers():
 
     pol, val = mcts_wrapper(lambda key, x, p, o: _Out)(None, None, None, 0)
     assert np.allclose(host(pol), np.log([[0.5, 0.5, 1e-8]])) and host(val).tolist() == [0.25]
+
+
+def test_policy_players():
+    """host.py:98-113, agent.py:101-111: players that ask a policy object, through GameHironaka"""
+    from hironaka_amd.agent import PolicyAgent
+    from hironaka_amd.host import PolicyHost
+
+    class AllCoordPolicy:
+        def predict(self, features):
+            assert features.shape[1:] == (10, 3) and bool((features[:, :-1, 0] >= features[:, 1:, 0]).all())
+            return torch.ones((features.shape[0], 3), device=features.device)
+
+    class FirstAxisPolicy:
+        def predict(self, inputs):
+            features, coords = inputs
+            return torch.argmax((coords > 0).to(torch.int32), dim=1).tolist()
+
+    start = torch.randint(0, 20, (32, 10, 3), generator=torch.Generator().manual_seed(3))
+    a = GameHironaka(HipPoints(start.clone()), PolicyHost(AllCoordPolicy()), PolicyAgent(FirstAxisPolicy()),
+                     scale_observation=False)
+    b = GameHironaka(HipPoints(start.clone()), AllCoordHost(), ChooseFirstAgent(), scale_observation=False)
+    for _ in range(12):
+        assert a.step() == b.step()
+        assert torch.equal(a.state.points, b.state.points)
+    assert len(a.move_history) == len(b.move_history) > 0
+    assert torch.equal(a.coord_history[0], b.coord_history[0]) and torch.equal(a.move_history[0], b.move_history[0])
