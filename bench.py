@@ -310,6 +310,45 @@ def main():
                "note": "one hk_step launch per env step (hk::fast_kernel<20,3,step>): f32 state + f32 [B,d] mask "
                        "+ i32 axis read from HBM, state + done + reward written back"}
 
+    # ---- SURVEY 8(d), config 2's second protocol: the agent draws its axis among the host's coordinates
+    # only, under the torch and the list sibling's semantics (illegal / finished games not shifted; list:
+    # survivors sorted + compacted after every step) -- fused 20-step rollouts and single hk_step launches ----
+    legal = None
+    if world == 1 and b == BATCH and not args.no_single_step:
+        legal = {"agent": "uniform over the host's subset (HK_AGENT_RANDOM_LEGAL)"}
+        cls_l = torch.randint(0, 2 ** d - d - 1, (b,), dtype=torch.int32, device="cuda")
+        axis_l = torch.zeros(b, dtype=torch.int32, device="cuda")  # coordinate 0 is in 3 of the 4 subsets
+        out_l = torch.empty_like(fresh)
+        for sem in ("torch", "list"):
+            fl = ops.make_flags(sem, noop_if_invalid=True, ignore_ended=True)
+
+            def roll_sem():
+                ops.rollout(state, EPISODE, SEED, done_count=done_count, initial=fresh, stages=stages, flags=fl,
+                            host_policy=A.HK_HOST_RANDOM, agent_policy=A.HK_AGENT_RANDOM_LEGAL)
+
+            def step_sem():
+                ops.step(fresh, cls_l, axis_l, stages=stages, flags=fl, out=out_l, want=("done", "reward"))
+
+            ts = []
+            for fn in (roll_sem, step_sem):
+                with torch.cuda.stream(side):
+                    fn()
+                    torch.cuda.synchronize()
+                    gl = capture(lambda: [fn() for _ in range(10)])
+                torch.cuda.synchronize()
+                gl.replay()
+                torch.cuda.synchronize()
+                l0, l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                l0.record()
+                for _ in range(10):
+                    gl.replay()
+                l1.record()
+                torch.cuda.synchronize()
+                ts.append(l0.elapsed_time(l1) / 1e3 / 100)
+            legal[sem] = {"fused_rollout_us_per_episode": ts[0] * 1e6, "fused_env_steps_per_s": b * EPISODE / ts[0],
+                          "hk_step_us": ts[1] * 1e6, "hk_step_env_steps_per_s": b / ts[1]}
+        done_count.zero_()
+
     # ---- same kernels at the batch that saturates one GPU (BASELINE configs[3]'s 524 288 games on ONE
     # device): one lane per game means 65 536 games are only 1024 instruction streams for 1024 SIMDs ----
     large = None
@@ -458,6 +497,8 @@ def main():
             out["boundary_step"] = api
         if large is not None:
             out["large_batch"] = large
+        if legal is not None:
+            out["legal_axis_torch_list_semantics"] = legal
         if config3 is not None:
             out["config3_dim4_50points"] = config3
         if world == 1 and not args.no_cpu_baseline:
