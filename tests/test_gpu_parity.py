@@ -402,6 +402,23 @@ def test_shard_invariance():
     assert torch.equal(full, torch.cat(parts))
 
 
+def test_config4_shards_equal_the_whole_batch():
+    """BASELINE configs[3] at full size on one device: 524 288 games as 8 rank shards of 65 536 (generation and
+    a 20-step rollout each with its rank's game_offset) == the unsharded batch, state for state, and the
+    shards' finished-game histograms add up to the whole batch's (what all_reduce_counts sums across ranks)"""
+    world, b = 8, 65536
+    full = ops.generate_points(world * b, 20, 3, 20, seed=42)
+    rec_full = ops.rollout(full, 20, 7, record=("game_length",))
+    total = torch.zeros_like(rec_full["done_count"])
+    for r in range(world):
+        part = ops.generate_points(b, 20, 3, 20, seed=42, game_offset=r * b)
+        rec = ops.rollout(part, 20, 7, game_offset=r * b, record=("game_length",))
+        assert torch.equal(part, full[r * b:(r + 1) * b]), r
+        assert torch.equal(rec["game_length"], rec_full["game_length"][r * b:(r + 1) * b]), r
+        total += rec["done_count"]
+    assert torch.equal(total, rec_full["done_count"])
+
+
 # ------------------------------------------------------------------------------------------
 # BASELINE sizes: oracle on a slice + size-independent properties on the whole batch
 # ------------------------------------------------------------------------------------------
