@@ -313,11 +313,16 @@ __device__ inline void fast_policy(const Params& prm, uint64_t gg, uint32_t step
 }
 
 // ---- the kernel: MODE is one of kModeStep / kModeRollout / kModeRolloutRec / kModeGenerate -------
-// HOT: the configuration of the JAX trainer's rollouts (shift + reposition + Newton polytope, JAX
-// semantics without behaviour flags, uniformly random host and agent) as compile-time constants.  A lone
-// wave per SIMD pays a fetch bubble for every taken branch, and the per-step tests of stages / flags /
-// policies are ~15 % of a fused rollout (measured: 43.5 -> 38.1 us per 20-step episode of 65 536 games).
-template <int M, int D, int MODE, bool HOT = false>
+// HOT: a rollout configuration as compile-time constants.  kHotJax: the JAX trainer's rollouts (shift +
+// reposition + Newton polytope, JAX semantics without behaviour flags, uniformly random host and agent);
+// kHotTorch: the same stages under the torch sibling's semantics (illegal axis / finished game not shifted)
+// with the agent drawing among the host's coordinates -- SURVEY 8(d)'s two protocols.  A lone wave per SIMD
+// pays a fetch bubble for every taken branch, and the per-step tests of stages / flags / policies are ~15 %
+// of a fused rollout (measured: 43.5 -> 38.1 us per 20-step episode of 65 536 games).
+constexpr int kHotNone = 0, kHotJax = 1, kHotTorch = 2;
+constexpr unsigned kHotTorchFlags = HK_SEM_TORCH | HK_FLAG_AXIS_NOOP_IF_INVALID | HK_FLAG_IGNORE_ENDED;
+
+template <int M, int D, int MODE, int HOT = kHotNone>
 __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1 : 2)) void fast_kernel(const float* in0, int64_t in_stride0, int batch0, int gpb0, const Params prm) {
   // in0 / in_stride0 / batch0 / gpb0 repeat prm.in / in_stride / batch / games_per_block as leading scalar
   // arguments: those are PRELOADED into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count), so the
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   const uint64_t gg = prm.game_offset + (uint64_t)g;
   float* mine = lds + lane * G::S;
   const float pad = (float)prm.pad;
-  const unsigned flags = HOT ? (unsigned)HK_SEM_JAX : prm.flags;
+  const unsigned flags = (HOT == kHotJax) ? (unsigned)HK_SEM_JAX : (HOT == kHotTorch) ? kHotTorchFlags : prm.flags;
   const unsigned stages = HOT ? (unsigned)(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON)
                               : (MODE == kModeGenerate) ? (prm.stages & ~HK_STAGE_SHIFT) : prm.stages;
   const float fill = ((flags & HK_SEM_MASK) == HK_SEM_JAX) ? -1.0f : pad;  // _jax_ops.py:65 does not forward pad
@@ -482,7 +487,8 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   uint32_t step0 = prm.step_offset;
   uint64_t seed = prm.seed;
   int host_policy = HOT ? (int)HK_HOST_RANDOM : prm.host_policy;
-  int agent_policy = HOT ? (int)HK_AGENT_RANDOM : prm.agent_policy;
+  int agent_policy = (HOT == kHotJax) ? (int)HK_AGENT_RANDOM
+                                      : (HOT == kHotTorch) ? (int)HK_AGENT_RANDOM_LEGAL : prm.agent_policy;
   // opaque to the optimiser: the values now "come from" the asm, so they stay in SGPRs (or a VGPR lane)
   // instead of being re-loaded from the kernel-argument / dispatch memory inside the loop
   if (HOT)
@@ -622,9 +628,12 @@ inline int fast_games_per_block(const Params& prm) {
   return kWave;
 }
 
-inline bool fast_hot_config(const Params& prm) {
-  return prm.stages == (HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON) && prm.flags == HK_SEM_JAX &&
-         prm.host_policy == HK_HOST_RANDOM && prm.agent_policy == HK_AGENT_RANDOM;
+inline int fast_hot_config(const Params& prm) {
+  if (prm.stages != (HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON) || prm.host_policy != HK_HOST_RANDOM)
+    return kHotNone;
+  if (prm.flags == HK_SEM_JAX && prm.agent_policy == HK_AGENT_RANDOM) return kHotJax;
+  if (prm.flags == kHotTorchFlags && prm.agent_policy == HK_AGENT_RANDOM_LEGAL) return kHotTorch;
+  return kHotNone;
 }
 
 template <int M, int D>
@@ -644,8 +653,11 @@ int launch_fast_t(Params prm, hipStream_t stream) {
                                         prm.r_done_out || prm.r_reward_out))
     hipLaunchKernelGGL((fast_kernel<M, D, kModeRolloutRec>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
                        prm.in_stride, prm.batch, prm.games_per_block, prm);
-  else if (prm.mode == kModeRollout && fast_hot_config(prm))
-    hipLaunchKernelGGL((fast_kernel<M, D, kModeRollout, true>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
+  else if (prm.mode == kModeRollout && fast_hot_config(prm) == kHotJax)
+    hipLaunchKernelGGL((fast_kernel<M, D, kModeRollout, kHotJax>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
+                       prm.in_stride, prm.batch, prm.games_per_block, prm);
+  else if (prm.mode == kModeRollout && fast_hot_config(prm) == kHotTorch)
+    hipLaunchKernelGGL((fast_kernel<M, D, kModeRollout, kHotTorch>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
                        prm.in_stride, prm.batch, prm.games_per_block, prm);
   else if (prm.mode == kModeRollout)
     hipLaunchKernelGGL((fast_kernel<M, D, kModeRollout>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,

@@ -7,6 +7,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -18,6 +19,7 @@ src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 HEADLINE_GRID = "65536"  # 1024 waves x 64 lanes = 65 536 games (BASELINE configs[1])
+HEADLINE_KERNEL = re.compile(r"fast_kernel<20, 3, 1, (1|true)>")  # hk::fast_kernel<20,3,rollout,kHotJax>
 
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
@@ -75,7 +77,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     for r in csv.DictReader(open(f[0])):
         if r["Grid_Size"] != HEADLINE_GRID:
             continue
-        if "fast_kernel<20, 3, 1" in r["Kernel_Name"]:
+        if HEADLINE_KERNEL.search(r["Kernel_Name"]):  # the JAX-configuration rollout kernel only
             e = roll[r["Dispatch_Id"]]
         elif "fast_kernel<20, 3, 0" in r["Kernel_Name"]:
             e = step[r["Dispatch_Id"]]

@@ -371,6 +371,31 @@ def test_rollout_matches_oracle(spec, force_generic):
             assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"])
 
 
+@pytest.mark.parametrize("spec", [(20, 3), (10, 3), (4, 3), (8, 4), (20, 4), (50, 4)])
+def test_compiled_rollout_configurations_match_oracle(spec):
+    """The two rollout configurations the register-resident kernels carry as compile-time constants (SURVEY
+    8d's protocols: JAX semantics + uniform axis; torch semantics + an axis among the host's coordinates,
+    illegal / finished games not shifted) without records -- the launches bench.py times -- against the
+    oracle, and the same requests with one flag more (which the runtime-configured kernel serves)"""
+    m, d = spec
+    p0 = CO.generate_points(1111, m, d, 20, 6)
+    stages = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON
+    torch_flags = ops.make_flags("torch", noop_if_invalid=True, ignore_ended=True)
+    for flags_p, flags_o, ap in (
+            (0, 0, A.HK_AGENT_RANDOM),
+            (torch_flags, CO.flags_of(sem="torch", noop_if_invalid=True, ignore_ended=True), A.HK_AGENT_RANDOM_LEGAL),
+            (ops.make_flags("torch", noop_if_invalid=True), CO.flags_of(sem="torch", noop_if_invalid=True),
+             A.HK_AGENT_RANDOM_LEGAL)):
+        for T in (1, 20):
+            want_p, want = CO.rollout(p0, T, 31, game_offset=5, host_policy=A.HK_HOST_RANDOM, agent_policy=ap,
+                                      stages=stages, flags=flags_o, record=False)
+            P = dev(p0.copy())
+            got = ops.rollout(P, T, 31, game_offset=5, host_policy=A.HK_HOST_RANDOM, agent_policy=ap, stages=stages,
+                              flags=flags_p)
+            assert np.array_equal(host(P), want_p), (flags_p, T)
+            assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"]), (flags_p, T)
+
+
 def test_rollout_equals_stepwise_launches():
     """T fused steps == T single-step launches fed the recorded actions (the two bench paths)"""
     P = ops.generate_points(4096, 20, 3, 20, seed=42)
