@@ -83,6 +83,9 @@ def main():
         pad = float(rng.choice([-1.0, -1.0, -1.0, -1e-8, -2.5]))
         force = int(rng.choice([0, 0, A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC]))
         noop, ign = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        if rng.integers(0, 4) == 0:  # the flag sets of the compiled rollout configurations
+            noop = ign = (sem == "torch")
+            pad = -1.0 if sem == "jax" else pad
         stages = int(rng.choice([1, 2, 4, 5, 7, 7, 7, 8, 15]))
         maxv = int(rng.choice([2, 3, 6, 20, 1000]))
         holes = float(rng.choice([0.0, 0.3, 0.8, 0.97]))
@@ -137,6 +140,14 @@ def main():
                 sys.exit(1)
         if not np.array_equal(rec["done_count"].cpu().numpy().astype(np.uint64), wrec["done_count"]):
             print("ROLLOUT MISMATCH done_count", cfg)
+            sys.exit(1)
+        # the same rollout without records: the plain rollout kernels (incl. the two compiled configurations)
+        Q2 = P.clone()
+        plain = ops.rollout(Q2, T, seed, game_offset=off, host_policy=hp, agent_policy=apol, stages=rstages,
+                            flags=flags_p, padding_value=pad)
+        if not (np.array_equal(Q2.cpu().numpy(), wp)
+                and np.array_equal(plain["done_count"].cpu().numpy().astype(np.uint64), wrec["done_count"])):
+            print("PLAIN ROLLOUT MISMATCH", cfg)
             sys.exit(1)
         n += 1
         if n % 200 == 0:
