@@ -303,12 +303,32 @@ def main():
         torch.cuda.synchronize()
         copy_gbps = 10 * 2 * big.numel() * 4 / (s0.elapsed_time(s1) / 1e3) / 1e9
         del big, dst
+        # ... and what a copy of exactly one state batch (15.7 MB in, 15.7 MB out: the traffic of one hk_step)
+        # takes as a kernel of its own, replayed from a hipGraph like the steps above
+        same = torch.empty_like(fresh)
+        with torch.cuda.stream(side):
+            same.copy_(fresh)
+            torch.cuda.synchronize()
+            g_copy = capture(lambda: [same.copy_(fresh) for _ in range(20)])
+        torch.cuda.synchronize()
+        g_copy.replay()
+        torch.cuda.synchronize()
+        s0.record()
+        for _ in range(10):
+            g_copy.replay()
+        s1.record()
+        torch.cuda.synchronize()
+        same_us = s0.elapsed_time(s1) * 1e3 / 200
+        del same
         gbps = b * algorithmic_bytes_per_step(m, d) / api_s / 1e9
         api = {"value": b / api_s, "unit": "env-steps/s per GPU", "us_per_step": api_s * 1e6,
                "steps": max(1, min(n_full, 50)) * EPISODE, "algorithmic_GBps": gbps,
                "frac_of_hbm_peak": gbps / HBM_PEAK_GBS, "device_copy_GBps": copy_gbps, "frac_of_device_copy": gbps / copy_gbps,
+               "state_copy_us": same_us,
                "note": "one hk_step launch per env step (hk::fast_kernel<20,3,step>): f32 state + f32 [B,d] mask "
-                       "+ i32 axis read from HBM, state + done + reward written back"}
+                       "+ i32 axis read from HBM, state + done + reward written back; device_copy_GBps = a 1 GiB "
+                       "device-to-device copy, state_copy_us = a copy kernel over one state batch (the same bytes as "
+                       "one hk_step without the actions and outcomes)"}
 
     # ---- SURVEY 8(d), config 2's second protocol: the agent draws its axis among the host's coordinates
     # only, under the torch and the list sibling's semantics (illegal / finished games not shifted; list:
