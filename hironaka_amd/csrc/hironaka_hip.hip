@@ -2,6 +2,7 @@
 // and launch.  No allocation, no synchronisation, no exceptions; every entry point returns a
 // status code.  gfx950 only.
 #include "hk_fast_kernel.h"
+#include "hk_duo_kernel.h"
 #include "hk_team_kernel.h"
 #include "hk_search.h"
 #include "hk_generic_kernel.h"
@@ -61,9 +62,16 @@ int launch_generic(Params& prm, int dtype, hipStream_t stream) {
 // kernel selection: register-resident specialisation -> team kernel (f32, dim 2..6, <= 64 rows; also the
 // specialised shapes on HK_FLAG_FORCE_TEAM) -> generic kernel (anything else: f64, dim > 6, > 64 rows,
 // HK_FLAG_FORCE_GENERIC, and the few mode / semantics combinations fast_supported / team_supported decline)
+static bool use_duo(const Params& prm) { return !(prm.flags & HK_FLAG_FORCE_ONE_LANE) && duo_wanted(prm); }
+
 int launch(Params& prm, int dtype, hipStream_t stream) {
   if (prm.batch == 0) return HK_OK;
-  if (fast_supported(prm, dtype)) return launch_fast(prm, stream);
+  if (fast_supported(prm, dtype)) {
+    const bool duo = use_duo(prm);
+    prm.flags &= ~HK_FLAG_FORCE_ONE_LANE;  // host-side only (the compiled rollout configurations compare flags)
+    return duo ? launch_duo(prm, stream) : launch_fast(prm, stream);
+  }
+  prm.flags &= ~HK_FLAG_FORCE_ONE_LANE;
   if (team_supported(prm, dtype)) {
     const int st = launch_team(prm, stream);
     if (st != HK_ERR_UNSUPPORTED) return st;
@@ -75,13 +83,28 @@ int launch(Params& prm, int dtype, hipStream_t stream) {
 int64_t planned_grid(Params prm, int dtype) {
   if (prm.batch == 0) return 0;
   if (fast_supported(prm, dtype)) {
-    const int gpb = fast_games_per_block(prm);
+    const int gpb = use_duo(prm) ? kDuoGames : fast_games_per_block(prm);
     return ((int64_t)prm.batch + gpb - 1) / gpb;
   }
   if (team_supported(prm, dtype) && plan_team(prm) == HK_OK)
     return ((int64_t)prm.batch + prm.games_per_block - 1) / prm.games_per_block;
   if (plan_generic(prm, dtype) != HK_OK) return 0;
   return ((int64_t)prm.batch + prm.games_per_block - 1) / prm.games_per_block;
+}
+
+// row length of the finished-game workspace for a geometry: an upper bound of the grids of all the kernel
+// variants that may serve it (records, policies and semantics choose among them per launch)
+int64_t count_slots(Params prm, int dtype) {
+  if (prm.batch == 0) return 0;
+  int64_t slots = planned_grid(prm, dtype);
+  if (dtype == HK_F32 && prm.d >= 2 && prm.d <= 6 && prm.m <= kTeam * kTeamSlots)
+    slots = std::max<int64_t>(slots, ((int64_t)prm.batch + kTeamGames - 1) / kTeamGames);
+  if (has_fast_path(prm.m, prm.d, dtype))
+    slots = std::max<int64_t>(slots, ((int64_t)prm.batch + kDuoGames - 1) / kDuoGames);
+  Params gen = prm;
+  if (plan_generic(gen, dtype) == HK_OK)
+    slots = std::max<int64_t>(slots, ((int64_t)prm.batch + gen.games_per_block - 1) / gen.games_per_block);
+  return slots;
 }
 
 int valid_coords_kind(int kind) {
@@ -329,14 +352,14 @@ static int params_from_rollout(const hk_rollout_desc* r, Params& prm) {
 uint64_t hk_rollout_workspace_bytes(const hk_rollout_desc* r) {
   Params prm{};
   if (params_from_rollout(r, prm) != HK_OK || prm.batch == 0) return 0;
-  return (uint64_t)planned_grid(prm, r->dtype) * (uint64_t)(r->steps + 1) * sizeof(uint32_t);
+  return (uint64_t)count_slots(prm, r->dtype) * (uint64_t)(r->steps + 1) * sizeof(uint32_t);
 }
 
 // workspace checks shared by hk_rollout and hk_rollout_reduce_counts
-static int counts_workspace(const hk_rollout_desc* r, int64_t grid, uint32_t** ws) {
+static int counts_workspace(const hk_rollout_desc* r, int64_t slots, uint32_t** ws) {
   if (!r->workspace) return HK_ERR_NULL;
   if (!aligned(r->workspace, 4)) return HK_ERR_ALIGN;
-  if (r->workspace_bytes < (uint64_t)grid * (uint64_t)(r->steps + 1) * sizeof(uint32_t)) return HK_ERR_SHAPE;
+  if (r->workspace_bytes < (uint64_t)slots * (uint64_t)(r->steps + 1) * sizeof(uint32_t)) return HK_ERR_SHAPE;
   *ws = (uint32_t*)r->workspace;
   return HK_OK;
 }
@@ -346,16 +369,17 @@ int hk_rollout(const hk_rollout_desc* r, void* stream) {
   const int st = params_from_rollout(r, prm);
   if (st != HK_OK) return st;
   if (prm.batch == 0) return HK_OK;
-  const int64_t grid = planned_grid(prm, r->dtype);
-  if (grid == 0) return HK_ERR_UNSUPPORTED;
+  if (planned_grid(prm, r->dtype) == 0) return HK_ERR_UNSUPPORTED;
+  const int64_t slots = count_slots(prm, r->dtype);
   const bool defer = (r->flags & HK_FLAG_DEFER_COUNTS) != 0;
   if (r->done_count || defer) {
-    const int ws = counts_workspace(r, grid, &prm.count_ws);
+    const int ws = counts_workspace(r, slots, &prm.count_ws);
     if (ws != HK_OK) return ws;
   }
+  prm.count_stride = (uint32_t)slots;
   const int ls = launch(prm, r->dtype, (hipStream_t)stream);
   if (ls != HK_OK || !r->done_count || defer) return ls;
-  return launch_count_reduce(prm.count_ws, (int)grid, r->steps, (unsigned long long*)r->done_count,
+  return launch_count_reduce(prm.count_ws, (int)slots, r->steps, (unsigned long long*)r->done_count,
                              (hipStream_t)stream);
 }
 
@@ -369,12 +393,12 @@ int hk_rollout_reduce_counts(const hk_rollout_desc* desc, void* stream) {
   if (st != HK_OK) return st;
   if (!r->done_count) return HK_ERR_NULL;
   if (prm.batch == 0) return HK_OK;
-  const int64_t grid = planned_grid(prm, r->dtype);
-  if (grid == 0) return HK_ERR_UNSUPPORTED;
+  const int64_t slots = count_slots(prm, r->dtype);
+  if (slots == 0) return HK_ERR_UNSUPPORTED;
   uint32_t* ws = nullptr;
-  const int wst = counts_workspace(r, grid, &ws);
+  const int wst = counts_workspace(r, slots, &ws);
   if (wst != HK_OK) return wst;
-  return launch_count_reduce(ws, (int)grid, r->steps, (unsigned long long*)r->done_count, (hipStream_t)stream);
+  return launch_count_reduce(ws, (int)slots, r->steps, (unsigned long long*)r->done_count, (hipStream_t)stream);
 }
 
 // ---- search tree operations --------------------------------------------------------------------------

@@ -53,7 +53,7 @@ struct Params {
   int32_t* num_points_out;
   int32_t* class_out;  // zeillinger operator
   // rollout
-  uint32_t* count_ws;  // [steps+1][gridDim.x] per-workgroup finished-game counts (or NULL)
+  uint32_t* count_ws;  // [steps+1][count_stride] per-workgroup finished-game counts (or NULL)
   void* obs_out;
   int32_t* r_host_class_out;
   int32_t* r_axis_out;
@@ -79,6 +79,9 @@ struct Params {
   int32_t lds_stride;       // elements per game in LDS (generic kernel)
   int32_t games_per_block;  // <= 64
   int32_t mode;
+  // row length of count_ws: the same for every kernel variant that may serve a geometry (>= any of their
+  // grids), so that deferred counts of different launches meet in one workspace
+  uint32_t count_stride;
 };
 
 // hipGetLastError() is sticky per host thread and other users of the runtime in this process

@@ -1,0 +1,506 @@
+// Two lanes per game: the rollout kernel for batches that do not fill the device.
+//
+// hk::fast_kernel holds a game in ONE lane, so 65 536 games are 1024 instruction streams for the 1024 SIMDs of
+// an MI355X, and a lone wave per SIMD issues an instruction only every ~7.7 cycles: the
+// vector ALUs idle half of the time and nothing overlaps the load / store bursts.  hk::duo_kernel deals the
+// live rows of a game alternately to a PAIR of lanes (compact rank r -> lane r & 1, slot r >> 1; 32 games per
+// wave), so the same batch is twice the waves, each with about half the instructions:
+//   * shift is per row; reposition / rescale reduce over a lane's own rows and meet the partner's result
+//     through one DPP exchange (quad_perm [1,0,3,2]) per coordinate;
+//   * the domination test: a lane runs its own rows' triangle, and of the cross pairs (mine a, partner's b)
+//     only those with a <= b, in BOTH directions -- the partner does the same from its side, so every cross
+//     pair is visited once (the diagonal twice, consistently); what a lane finds out about the partner's rows
+//     travels back through one exchange per slot;
+//   * everything else (policies, finished-game counts, the exactness guard and its whole-wave fallback on the
+//     generic routines, bucketed straight-line bodies, re-gathering when the widest game narrows) follows
+//     hk_fast_kernel.h.
+// Row order (which of two equal rows survives, _jax_ops.py:15-40) is the compact rank, i.e. the physical row
+// order, exactly as in the one-lane kernel.
+#pragma once
+
+#include "hk_fast_kernel.h"
+
+namespace hk {
+
+constexpr int kDuoGames = kWave / 2;
+
+// the partner lane's value: DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ int duo_other_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ float duo_other(float v) { return __int_as_float(duo_other_i(__float_as_int(v))); }
+
+template <int M, int D>
+struct DuoGeom {
+  using G = FastGeom<M, D>;
+  static constexpr int CH = (G::C + 1) / 2;                       // slots per lane
+  static constexpr int QH = (kDuoGames * G::Q + kWave - 1) / kWave;  // slab chunks per lane
+};
+
+// ---- slab I/O for 32 games per wave (see hk_fast_kernel.h: all requests in flight before the first use) --
+template <int M, int D>
+struct DuoSlabRegs {
+  typename VecOf<FastGeom<M, D>::W>::type v[DuoGeom<M, D>::QH];
+};
+
+template <int M, int D, bool CONTIG>
+__device__ __forceinline__ void duo_slab_issue_impl(DuoSlabRegs<M, D>& r, const float* base, int64_t in_stride,
+                                                    int ngames, int lane) {
+  using G = FastGeom<M, D>;
+  using V = typename VecOf<G::W>::type;
+  const int total = ngames * G::Q;
+#pragma unroll
+  for (int it = 0; it < DuoGeom<M, D>::QH; ++it) {
+    int q = lane + it * kWave;
+    q = q < total ? q : total - 1;
+    r.v[it] = *reinterpret_cast<const V*>(base + slab_chunk_global<M, D, CONTIG>(q, in_stride));
+  }
+}
+
+template <int M, int D>
+__device__ __forceinline__ void duo_slab_issue(DuoSlabRegs<M, D>& r, const float* in, int64_t in_stride, int64_t g0,
+                                               int ngames, int lane) {
+  const float* base = in + g0 * in_stride;
+  if (in_stride == FastGeom<M, D>::N) duo_slab_issue_impl<M, D, true>(r, base, in_stride, ngames, lane);
+  else duo_slab_issue_impl<M, D, false>(r, base, in_stride, ngames, lane);
+}
+
+template <int M, int D>
+__device__ __forceinline__ void duo_slab_commit(DuoSlabRegs<M, D>& r, float* lds, int ngames, int lane) {
+  using G = FastGeom<M, D>;
+  using V = typename VecOf<G::W>::type;
+  const int total = ngames * G::Q;
+#pragma unroll
+  for (int it = 0; it < DuoGeom<M, D>::QH; ++it) asm volatile("" : "+v"(r.v[it]));
+#pragma unroll
+  for (int it = 0; it < DuoGeom<M, D>::QH; ++it) {
+    const int q = lane + it * kWave;
+    if (q < total) *reinterpret_cast<V*>(lds + slab_chunk_lds<M, D>(q)) = r.v[it];
+  }
+}
+
+template <int M, int D, bool CONTIG>
+__device__ __forceinline__ void duo_store_slab_impl(const float* lds, float* base, int64_t out_stride, int ngames,
+                                                    int lane) {
+  using G = FastGeom<M, D>;
+  using V = typename VecOf<G::W>::type;
+  constexpr int QH = DuoGeom<M, D>::QH;
+  const int total = ngames * G::Q;
+  V v[QH];
+#pragma unroll
+  for (int it = 0; it < QH; ++it) {  // the image holds kDuoGames games whatever ngames is
+    int q = lane + it * kWave;
+    q = q < kDuoGames * G::Q ? q : kDuoGames * G::Q - 1;
+    v[it] = *reinterpret_cast<const V*>(lds + slab_chunk_lds<M, D>(q));
+  }
+#pragma unroll
+  for (int it = 0; it < QH; ++it) asm volatile("" : "+v"(v[it]));
+#pragma unroll
+  for (int it = 0; it < QH; ++it) {
+    const int q = lane + it * kWave;
+    if (q < total) *reinterpret_cast<V*>(base + slab_chunk_global<M, D, CONTIG>(q, out_stride)) = v[it];
+  }
+}
+
+template <int M, int D>
+__device__ inline void duo_store_slab(const float* lds, float* out, int64_t out_stride, int64_t g0, int ngames,
+                                      int lane) {
+  float* base = out + g0 * out_stride;
+  if (out_stride == FastGeom<M, D>::N) duo_store_slab_impl<M, D, true>(lds, base, out_stride, ngames, lane);
+  else duo_store_slab_impl<M, D, false>(lds, base, out_stride, ngames, lane);
+}
+
+// ---- image <-> registers ----------------------------------------------------------------------------------
+// the set bits of `mask` in ascending order are the game's live rows; lane h takes the ranks h, h + 2, ...
+template <int M, int CH, int D>
+__device__ __forceinline__ void duo_gather(float (&q)[CH * D], const float* mine, uint32_t mask, int smax, int h) {
+  unrolled_while<0, CH>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (s >= smax) return false;
+    const bool has0 = mask != 0;
+    const int b0 = has0 ? mask_first(mask) : 0;
+    mask &= mask - 1;
+    const bool has1 = mask != 0;
+    const int b1 = has1 ? mask_first(mask) : 0;
+    mask &= mask - 1;
+    const bool has = h ? has1 : has0;
+    const float* row = mine + (h ? b1 : b0) * D;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const float v = row[k];
+      q[s * D + k] = has ? v : INFINITY;
+    }
+    return true;
+  });
+}
+
+// the lane's live rows back to their slots; returns the mask of the GAME's slots still alive
+template <int M, int CH, int D>
+__device__ __forceinline__ uint32_t duo_scatter(const float (&q)[CH * D], float* mine, uint32_t mask, int smax, int h) {
+  uint32_t alive = 0;
+  unrolled_while<0, CH>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (s >= smax) return false;
+    const bool has0 = mask != 0;
+    const int b0 = has0 ? mask_first(mask) : 0;
+    mask &= mask - 1;
+    const bool has1 = mask != 0;
+    const int b1 = has1 ? mask_first(mask) : 0;
+    mask &= mask - 1;
+    const bool has = h ? has1 : has0;
+    const int slot = h ? b1 : b0;
+    if (has && q[s * D] < INFINITY) {
+      alive |= 1u << slot;
+      float* row = mine + slot * D;
+#pragma unroll
+      for (int k = 0; k < D; ++k) row[k] = q[s * D + k];
+    }
+    return true;
+  });
+  return alive | (uint32_t)duo_other_i((int)alive);
+}
+
+// ---- the stages on NB slots per lane ----------------------------------------------------------------------
+template <int CH, int D, int NB>
+__device__ __forceinline__ void d_reposition(float (&q)[CH * D], unsigned flags) {
+  const bool jax_sem = (flags & HK_SEM_MASK) == HK_SEM_JAX;
+  float mn[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) mn[k] = INFINITY;
+#pragma unroll
+  for (int r = 0; r < NB; ++r)
+#pragma unroll
+    for (int k = 0; k < D; ++k) mn[k] = hk_fmin(mn[k], q[r * D + k]);
+  float sub[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    mn[k] = hk_fmin(mn[k], duo_other(mn[k]));
+    sub[k] = (mn[k] < INFINITY && (!jax_sem || mn[k] > 0.0f)) ? mn[k] : 0.0f;  // see b_reposition
+  }
+#pragma unroll
+  for (int r = 0; r < NB; ++r)
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[r * D + k] = q[r * D + k] - sub[k];
+}
+
+template <int CH, int D, int NB>
+__device__ __forceinline__ void d_rescale(float (&q)[CH * D], unsigned flags) {
+  const bool jax_sem = (flags & HK_SEM_MASK) == HK_SEM_JAX;
+  float mx = -1.0f;
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    const bool live = q[r * D] < INFINITY;
+#pragma unroll
+    for (int k = 0; k < D; ++k) mx = hk_fmax(mx, live ? q[r * D + k] : -1.0f);
+  }
+  mx = hk_fmax(mx, duo_other(mx));
+  const bool skip = jax_sem ? (mx <= 1e-8f) : (mx < 0.0f);
+  const float div = (skip || mx == 0.0f) ? 1.0f : mx;
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    const bool live = q[r * D] < INFINITY;
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[r * D + k] = live ? q[r * D + k] / div : INFINITY;
+  }
+}
+
+// _jax_ops.py:15-73 across the pair.  Own rows i < j as in b_newton (rank 2i+h < 2j+h).  Cross pairs (mine a,
+// partner's b) with a <= b: my rank 2a+h, the partner's 2b+1-h, so my row is the earlier one unless a == b and
+// h == 1.  With t = max_k(mine - other), u = min_k(mine - other):
+//   mine earlier:  other removed iff t <= 0;            mine removed iff u >= 0 and t > 0
+//   other earlier: other removed iff t <= 0 and u < 0;  mine removed iff u >= 0
+// acc[] <= 0 marks my row removed; oth[] <= 0 marks the partner's slot removed (sent back at the end).
+template <int CH, int D, int NB>
+__device__ __forceinline__ void d_newton(float (&q)[CH * D], int h) {
+  float acc[NB], oth[NB];
+#pragma unroll
+  for (int r = 0; r < NB; ++r) acc[r] = oth[r] = INFINITY;
+#pragma unroll
+  for (int i = 0; i + 1 < NB; ++i) {
+#pragma unroll
+    for (int j = i + 1; j < NB; ++j) {
+      float t, u;
+      diff_extrema<D>(&q[i * D], &q[j * D], t, u);
+      acc[j] = hk_fmin(acc[j], t);
+      acc[i] = hk_fmin(acc[i], (t > 0.0f) ? -u : 1.0f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const bool late = h != 0;  // on the diagonal the partner's row is the earlier one
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    float o[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) o[k] = duo_other(q[b * D + k]);
+    {  // diagonal
+      float t, u;
+      diff_extrema<D>(&q[b * D], o, t, u);
+      acc[b] = hk_fmin(acc[b], (t > 0.0f || late) ? -u : 1.0f);
+      oth[b] = hk_fmin(oth[b], (u < 0.0f || !late) ? t : 1.0f);
+    }
+#pragma unroll
+    for (int a = 0; a < b; ++a) {
+      float t, u;
+      diff_extrema<D>(&q[a * D], o, t, u);
+      oth[b] = hk_fmin(oth[b], t);
+      acc[a] = hk_fmin(acc[a], (t > 0.0f) ? -u : 1.0f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    const bool removed = hk_fmin(acc[r], duo_other(oth[r])) <= 0.0f;
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[r * D + k] = removed ? INFINITY : q[r * D + k];
+  }
+}
+
+// one transition on slots [0, NB) of both lanes; returns the GAME's number of live rows
+template <int CH, int D, int NB>
+__device__ __forceinline__ int d_stages(float (&q)[CH * D], const float (&c)[D], int axis, int np, int h,
+                                        unsigned flags, unsigned stages) {
+  if (stages & HK_STAGE_SHIFT) b_shift<CH, D, NB>(q, c, axis, np, flags);
+  if (stages & HK_STAGE_REPOSITION) d_reposition<CH, D, NB>(q, flags);
+  if (stages & HK_STAGE_NEWTON) d_newton<CH, D, NB>(q, h);
+  if (stages & HK_STAGE_RESCALE) d_rescale<CH, D, NB>(q, flags);
+  int n = 0;
+#pragma unroll
+  for (int r = 0; r < NB; ++r) n += (q[r * D] < INFINITY) ? 1 : 0;
+  return n + duo_other_i(n);
+}
+
+template <int CH, int D, int NB>
+struct DuoStagesFor {
+  static constexpr int kNext = (NB < 6) ? NB + 1 : NB + 2;
+  static __device__ __forceinline__ int run(float (&q)[CH * D], int smax, const float (&c)[D], int axis, int np,
+                                            int h, unsigned flags, unsigned stages) {
+    if constexpr (NB >= CH) {
+      return d_stages<CH, D, CH>(q, c, axis, np, h, flags, stages);
+    } else {
+      if (smax <= NB) return d_stages<CH, D, NB>(q, c, axis, np, h, flags, stages);
+      return DuoStagesFor<CH, D, kNext>::run(q, smax, c, axis, np, h, flags, stages);
+    }
+  }
+};
+
+// ---- the kernel: fused rollouts without records (MODE kModeRollout) and single steps with the caller's actions
+// (kModeStep: hk_step) ---------------------------------------------------------------------------------------
+template <int M, int D, int MODE, int HOT = kHotNone>
+__global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t in_stride0, int batch0,
+                                                       const Params prm) {
+  constexpr bool kRoll = MODE == kModeRollout;
+  using G = FastGeom<M, D>;
+  constexpr int CH = DuoGeom<M, D>::CH;
+  static_assert(M <= 32, "the live mask of a game travels as 32 bits");
+  __shared__ __align__(16) float lds[kDuoGames * G::S];
+  __shared__ float cbuf[kDuoGames * D];  // slow path only
+  const int lane = threadIdx.x;
+  const int h = lane & 1, gi = lane >> 1;
+  const int64_t g0 = (int64_t)blockIdx.x * kDuoGames;
+  const int64_t left = (int64_t)batch0 - g0;
+  const int ngames = (int)(left < kDuoGames ? left : kDuoGames);
+  const bool active = gi < ngames;
+  const bool leader = active && h == 0;
+  const int64_t g = g0 + gi;
+  DuoSlabRegs<M, D> slab;
+  duo_slab_issue<M, D>(slab, in0, in_stride0, g0, ngames, lane);
+  const uint64_t gg = prm.game_offset + (uint64_t)g;
+  float* mine = lds + gi * G::S;
+  const float pad = (float)prm.pad;
+  const unsigned flags = (HOT == kHotJax) ? (unsigned)HK_SEM_JAX : (HOT == kHotTorch) ? kHotTorchFlags : prm.flags;
+  const unsigned stages = HOT ? (unsigned)(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON) : prm.stages;
+  const float fill = ((flags & HK_SEM_MASK) == HK_SEM_JAX) ? -1.0f : pad;
+  const int nsteps = kRoll ? prm.steps : 1;
+  PolicyCache pcache;
+  float c[D];
+  int axis_in = -1;
+#pragma unroll
+  for (int k = 0; k < D; ++k) c[k] = 0.0f;
+  // step mode: the action loads join the slab's requests in flight (both lanes of a pair fetch them)
+  RawActions<D> raw;
+  const bool fetch_actions = !kRoll && (stages & HK_STAGE_SHIFT) && active;
+  if (fetch_actions) fast_fetch_actions<D>(prm, g, M, raw);
+  duo_slab_commit<M, D>(slab, lds, ngames, lane);
+  if (fetch_actions) fast_decode_actions<D>(prm, raw, c, axis_in);
+  __syncthreads();
+
+  // ---- live rows, exactness guard (both lanes of a pair scan the whole game) --------------------------------
+  uint32_t gmask;
+  bool ok;
+  scan_image<M, D>(mine, fill, gmask, ok);
+  if (!active) {
+    gmask = 0;
+    ok = true;
+  }
+  int np = mask_pop(gmask);
+  int nmax = wave_max(np, M);
+  const bool exact = (fill == pad) && __all(ok) && nmax <= G::C;
+
+  if (!exact) {
+    // ---- slow path (whole wave): the pair's first lane runs the exact generic routines on the image ----------
+    float* cs = cbuf + gi * D;
+    np = leader ? num_points<float>(mine, M, D) : 2;
+    int length = (np < 2) ? 0 : -1;
+    if (kRoll && prm.count_ws) {
+      const unsigned long long b0 = __ballot(leader && np < 2);
+      if (lane == 0) count_add(prm.count_ws + blockIdx.x, (uint32_t)__popcll(b0));
+    }
+    for (int t = 0; t < nsteps; ++t) {
+      int axis = axis_in, cls = 0;
+      if (kRoll) {
+        uint32_t mask;
+        const int zc = (prm.host_policy == HK_HOST_ZEILLINGER && leader) ? zeillinger_game<float>(mine, prm.m, prm.d) : 0;
+        fast_policy<D>(prm, gg, prm.step_offset + (uint32_t)t, pcache, cls, axis, mask, zc);
+        if (leader)
+          for (int k = 0; k < prm.d; ++k) cs[k] = (float)((mask >> k) & 1u);
+      } else if ((stages & HK_STAGE_SHIFT) && leader) {
+        load_coords<float>(prm, g, cs);
+      }
+      const bool prev_done = np < 2;
+      if (leader) {
+        stages_game<float>(mine, prm.m, prm.d, cs, axis, pad, stages, flags);
+        np = num_points<float>(mine, prm.m, prm.d);
+      }
+      const bool done = np < 2;
+      if (done && length < 0) length = t + 1;
+      if (kRoll && prm.count_ws) {
+        const unsigned long long bd = __ballot(leader && done);
+        if (lane == 0) count_add(prm.count_ws + (size_t)(t + 1) * prm.count_stride + blockIdx.x, (uint32_t)__popcll(bd));
+      }
+      if (!kRoll && leader) {
+        if (prm.done_out) prm.done_out[g] = done;
+        if (prm.prev_done_out) prm.prev_done_out[g] = prev_done;
+        if (prm.reward_out) prm.reward_out[g] = prm.reward_sign * (float)(done && !prev_done);
+        if (prm.num_points_out) prm.num_points_out[g] = np;
+      }
+    }
+    if (kRoll && leader && prm.game_length_out) prm.game_length_out[g] = length;
+    __syncthreads();
+    duo_store_slab<M, D>(lds, (float*)prm.out, prm.out_stride, g0, ngames, lane);
+    return;
+  }
+
+  // ---- the pair's rows ----------------------------------------------------------------------------------
+  int smax = (nmax + 1) >> 1;
+  float q[CH * D];
+#pragma unroll
+  for (int e = 0; e < CH * D; ++e) q[e] = INFINITY;
+  duo_gather<M, CH, D>(q, mine, gmask, smax, h);
+  if (!active) np = 2;
+  int length = (np < 2) ? 0 : -1;
+  if (kRoll && prm.count_ws) {
+    const unsigned long long b0 = __ballot(leader && np < 2);
+    if (lane == 0) count_add(prm.count_ws + blockIdx.x, (uint32_t)__popcll(b0));
+  }
+  uint32_t* count_slot = (kRoll && prm.count_ws) ? prm.count_ws + blockIdx.x : nullptr;
+  uint32_t count_stride = prm.count_stride;
+  uint32_t step0 = prm.step_offset;
+  uint64_t seed = prm.seed;
+  int host_policy = HOT ? (int)HK_HOST_RANDOM : prm.host_policy;
+  int agent_policy = (HOT == kHotJax) ? (int)HK_AGENT_RANDOM
+                                      : (HOT == kHotTorch) ? (int)HK_AGENT_RANDOM_LEGAL : prm.agent_policy;
+  if (HOT)
+    asm volatile("" : "+s"(count_slot), "+s"(count_stride), "+s"(step0), "+s"(seed));
+  else
+    asm volatile("" : "+s"(count_slot), "+s"(count_stride), "+s"(step0), "+s"(seed), "+s"(host_policy),
+                 "+s"(agent_policy));
+  for (int t = 0; t < nsteps; ++t) {
+    int axis = axis_in, cls = 0;
+    if (kRoll) {
+      uint32_t mask;
+      fast_policy<D>(seed, host_policy, agent_policy, gg, step0 + (uint32_t)t, pcache, cls, axis, mask, 0);
+#pragma unroll
+      for (int k = 0; k < D; ++k) c[k] = (float)((mask >> k) & 1u);
+    }
+    const bool prev_done = np < 2;
+    np = DuoStagesFor<CH, D, 1>::run(q, smax, c, axis, np, h, flags, stages);
+    if (!active) np = 2;
+    const bool done = np < 2;
+    if (done && length < 0) length = t + 1;
+    if (!kRoll && leader) {
+      if (prm.done_out) prm.done_out[g] = done;
+      if (prm.prev_done_out) prm.prev_done_out[g] = prev_done;
+      if (prm.reward_out) prm.reward_out[g] = prm.reward_sign * (float)(done && !prev_done);
+      if (prm.num_points_out) prm.num_points_out[g] = np;
+    }
+    if (count_slot) {
+      const unsigned long long bd = __ballot(leader && done);
+      if (lane == 0) count_add(count_slot + (size_t)(t + 1) * count_stride, (uint32_t)__popcll(bd));
+    }
+    // re-deal the rows when the widest game of the wave fits fewer slots per lane
+    if (t + 1 < nsteps && !__any(active && ((np + 1) >> 1) >= smax)) {
+      __syncthreads();
+      gmask = duo_scatter<M, CH, D>(q, mine, gmask, smax, h);
+      __syncthreads();
+      const int sprev = smax;
+      nmax = wave_max(active ? np : 0, 2 * smax - 2);
+      smax = (nmax + 1) >> 1;
+      duo_gather<M, CH, D>(q, mine, gmask, sprev, h);  // slots [smax, sprev) become holes again
+    }
+  }
+  if (kRoll && leader && prm.game_length_out) prm.game_length_out[g] = length;
+
+  // ---- publish: pad everywhere, live rows back in their slots --------------------------------------------------
+  __syncthreads();
+  if (h == 0) fill_image<M, D>(mine, pad);
+  __syncthreads();
+  duo_scatter<M, CH, D>(q, mine, gmask, smax, h);
+  __syncthreads();
+  duo_store_slab<M, D>(lds, (float*)prm.out, prm.out_stride, g0, ngames, lane);
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------
+// rollouts without records on a shape with a register-resident specialisation, when the batch leaves SIMDs
+// short of a second wave under the one-lane kernel
+inline bool duo_wanted(const Params& prm) {
+  static const int forced = [] {  // tuning hook (scripts/probe_variants.py): HK_DUO=0|1 overrides the heuristic
+    const char* e = getenv("HK_DUO");
+    return e ? atoi(e) : -1;
+  }();
+  if ((prm.mode != kModeRollout && prm.mode != kModeStep) || prm.m > 32) return false;
+  if (prm.mode == kModeStep && (prm.class_out || (prm.stages & kStageFeatureSorts))) return false;
+  if (prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out) return false;
+  if (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER) return false;
+  if ((prm.stages & HK_STAGE_NEWTON) &&
+      ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)))
+    return false;
+  if (forced >= 0) return forced != 0;
+  // measured (scripts/probe_duo.py): ahead while the one-lane kernel leaves SIMDs short of a second wave --
+  // up to ~65 536 games, and at any size for the shapes whose one-lane kernel runs one wave per SIMD
+  return prm.batch <= 98304 || prm.m * prm.d > 64;
+}
+
+template <int M, int D>
+int launch_duo_t(Params prm, hipStream_t stream) {
+  const unsigned grid = (unsigned)(((int64_t)prm.batch + kDuoGames - 1) / kDuoGames);
+  prm.games_per_block = kDuoGames;
+  launch_prepare();
+  const int hot = prm.mode == kModeRollout ? fast_hot_config(prm) : kHotNone;
+  if (prm.mode == kModeStep)
+    hipLaunchKernelGGL((duo_kernel<M, D, kModeStep>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
+                       prm.in_stride, prm.batch, prm);
+  else if (hot == kHotJax)
+    hipLaunchKernelGGL((duo_kernel<M, D, kModeRollout, kHotJax>), dim3(grid), dim3(kWave), 0, stream,
+                       (const float*)prm.in, prm.in_stride, prm.batch, prm);
+  else if (hot == kHotTorch)
+    hipLaunchKernelGGL((duo_kernel<M, D, kModeRollout, kHotTorch>), dim3(grid), dim3(kWave), 0, stream,
+                       (const float*)prm.in, prm.in_stride, prm.batch, prm);
+  else
+    hipLaunchKernelGGL((duo_kernel<M, D, kModeRollout>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
+                       prm.in_stride, prm.batch, prm);
+  return launch_status();
+}
+
+// instantiated next to the one-lane specialisations (hk_fast_spec.hip); the dispatcher lives in the main unit
+#ifndef HK_SPEC_TU
+#define HK_X(M_, D_) extern template int launch_duo_t<M_, D_>(Params, hipStream_t);
+HK_FAST_SPECS(HK_X)
+#undef HK_X
+
+inline int launch_duo(const Params& prm, hipStream_t stream) {
+#define HK_X(M_, D_) if (prm.m == M_ && prm.d == D_) return launch_duo_t<M_, D_>(prm, stream);
+  HK_FAST_SPECS(HK_X)
+#undef HK_X
+  return HK_ERR_UNSUPPORTED;
+}
+#endif
+
+}  // namespace hk

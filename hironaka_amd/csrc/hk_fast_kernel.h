@@ -443,7 +443,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
         }
         if (prm.count_ws) {
           const unsigned long long bd = __ballot(active && done);
-          if (lane == 0) count_add(prm.count_ws + (size_t)(t + 1) * gridDim.x + blockIdx.x, (uint32_t)__popcll(bd));
+          if (lane == 0) count_add(prm.count_ws + (size_t)(t + 1) * prm.count_stride + blockIdx.x, (uint32_t)__popcll(bd));
         }
       } else if (kStep && active) {
         if (prm.done_out) prm.done_out[g] = done;
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   const bool want_records = kRec && (prm.r_host_class_out || prm.r_axis_out ||
                                                        prm.r_done_out || prm.r_reward_out);
   uint32_t* count_slot = (kRoll && prm.count_ws) ? prm.count_ws + blockIdx.x : nullptr;
-  uint32_t count_stride = gridDim.x;
+  uint32_t count_stride = prm.count_stride;
   uint32_t step0 = prm.step_offset;
   uint64_t seed = prm.seed;
   int host_policy = HOT ? (int)HK_HOST_RANDOM : prm.host_policy;
@@ -705,16 +705,28 @@ inline int launch_fast(const Params& prm, hipStream_t stream) {
 
 #ifndef HK_SPEC_TU  // the per-shape translation units hold only their own specialisations
 // ---- finished-game counters: per-workgroup partials -> done_count ---------------------------------
-// block t sums count_ws[t][0..nblocks), adds it to done_count[t] (steps+1 atomics in total instead of
-// (steps+1) * nblocks on one cache line) and leaves the partials zeroed for the next launches.
+// block (t, seg) sums a segment of count_ws[t][0..nblocks) -- all of its loads in flight together -- adds it
+// to done_count[t] (a handful of atomics per step instead of nblocks on one cache line) and leaves the
+// partials zeroed for the next launches.
+constexpr int kCountSeg = 2048;  // entries per block: 8 per thread
+
 __global__ __launch_bounds__(256) void count_reduce_kernel(uint32_t* ws, int nblocks,
                                                            unsigned long long* done_count) {
   __shared__ unsigned long long part[256 / kWave];
   uint32_t* row = ws + (size_t)blockIdx.x * nblocks;
+  const int i0 = blockIdx.y * kCountSeg + threadIdx.x;
+  uint32_t v[kCountSeg / 256];
+#pragma unroll
+  for (int k = 0; k < kCountSeg / 256; ++k) {
+    const int i = i0 + k * 256;
+    v[k] = (i < nblocks) ? row[i] : 0u;
+  }
   unsigned long long s = 0;
-  for (int i = threadIdx.x; i < nblocks; i += 256) {
-    s += row[i];
-    row[i] = 0;
+#pragma unroll
+  for (int k = 0; k < kCountSeg / 256; ++k) {
+    const int i = i0 + k * 256;
+    if (v[k]) row[i] = 0;
+    s += v[k];
   }
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) s += __shfl_down(s, off, kWave);
@@ -730,7 +742,8 @@ __global__ __launch_bounds__(256) void count_reduce_kernel(uint32_t* ws, int nbl
 inline int launch_count_reduce(uint32_t* ws, int nblocks, int steps, unsigned long long* done_count,
                                hipStream_t stream) {
   launch_prepare();
-  hipLaunchKernelGGL(count_reduce_kernel, dim3(steps + 1), dim3(256), 0, stream, ws, nblocks, done_count);
+  hipLaunchKernelGGL(count_reduce_kernel, dim3(steps + 1, (nblocks + kCountSeg - 1) / kCountSeg), dim3(256), 0,
+                     stream, ws, nblocks, done_count);
   return launch_status();
 }
 

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kWave) void generic_kernel(const Params prm) {
     }
     if (prm.count_ws) {
       const unsigned long long bd = __ballot(active && done);
-      if (lane == 0) count_add(prm.count_ws + (size_t)(t + 1) * gridDim.x + blockIdx.x, (uint32_t)__popcll(bd));
+      if (lane == 0) count_add(prm.count_ws + (size_t)(t + 1) * prm.count_stride + blockIdx.x, (uint32_t)__popcll(bd));
     }
     __syncthreads();
   }

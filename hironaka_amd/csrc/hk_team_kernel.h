@@ -529,7 +529,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
         }
         if (prm.count_ws) {
           const unsigned long long bd = __ballot(leader && done);
-          if (lane == 0) count_add(prm.count_ws + (size_t)(t + 1) * gridDim.x + blockIdx.x, (uint32_t)__popcll(bd));
+          if (lane == 0) count_add(prm.count_ws + (size_t)(t + 1) * prm.count_stride + blockIdx.x, (uint32_t)__popcll(bd));
         }
       } else if (kStep && leader) {
         if (prm.done_out) prm.done_out[g] = done;
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
       }
       if (prm.count_ws) {
         const unsigned long long bd = __ballot(leader && done);
-        if (lane == 0) count_add(prm.count_ws + (size_t)(t + 1) * gridDim.x + blockIdx.x, (uint32_t)__popcll(bd));
+        if (lane == 0) count_add(prm.count_ws + (size_t)(t + 1) * prm.count_stride + blockIdx.x, (uint32_t)__popcll(bd));
       }
       // squeeze when the widest game of the wave got narrower: live rows to their new ranks in the
       // region, then every lane takes back rows 4s+tl

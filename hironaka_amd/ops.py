@@ -11,6 +11,7 @@ _list_ops.py on padded arrays).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import Dict, Optional, Sequence, Tuple
 
@@ -22,6 +23,22 @@ from ._lib import check, lib
 _TORCH2HK = {torch.float32: A.HK_F32, torch.float64: A.HK_F64, torch.int32: A.HK_I32,
              torch.int64: A.HK_I64, torch.uint8: A.HK_U8, torch.bool: A.HK_U8}
 ALL_STAGES = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON | A.HK_STAGE_RESCALE
+
+
+# kernel-selection flags OR-ed into every step / rollout descriptor (tests: `with ops.forced(...)`)
+_forced_flags = 0
+
+
+@contextlib.contextmanager
+def forced(flags: int):
+    """Run the enclosed calls with kernel-selection flags (HK_FLAG_FORCE_ONE_LANE / _TEAM / _GENERIC) added to
+    every step and rollout launch -- the results must not depend on them."""
+    global _forced_flags
+    before, _forced_flags = _forced_flags, _forced_flags | flags
+    try:
+        yield
+    finally:
+        _forced_flags = before
 
 
 def make_flags(sem: str = "jax", noop_if_invalid: bool = False, ignore_ended: bool = False,
@@ -164,7 +181,7 @@ def step(points: torch.Tensor, coords=None, axis=None, *, stages: int, flags: in
     s.num_points_out = res["num_points"].data_ptr() if "num_points" in res else None
     s.padding_value, s.reward_sign = float(padding_value), float(reward_sign)
     s.batch, s.max_points, s.dim, s.dtype = b, m, d, _TORCH2HK[pts.dtype]
-    s.stages, s.flags = stages, flags
+    s.stages, s.flags = stages, flags | _forced_flags
     with torch.cuda.device(dev):
         check(lib().hk_step(C.byref(s), _stream(pts)), "hk_step")
     if out is None and orig != out_t.dtype:
@@ -334,7 +351,7 @@ def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
 def _geometry_desc(batch: int, steps: int, spec: Tuple[int, int], dtype, flags: int) -> "A.hk_rollout_desc":
     r = A.hk_rollout_desc()
     r.batch, r.max_points, r.dim, r.dtype, r.steps = batch, spec[0], spec[1], _TORCH2HK[dtype], steps
-    r.host_policy, r.agent_policy, r.flags = A.HK_HOST_RANDOM, A.HK_AGENT_RANDOM, flags
+    r.host_policy, r.agent_policy, r.flags = A.HK_HOST_RANDOM, A.HK_AGENT_RANDOM, flags | _forced_flags
     r.stages = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON
     return r
 
@@ -426,7 +443,7 @@ def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0
     r.seed, r.game_offset, r.step_offset = seed, game_offset, step_offset
     r.padding_value, r.reward_sign = float(padding_value), float(reward_sign)
     r.batch, r.max_points, r.dim, r.dtype, r.steps = b, m, d, _TORCH2HK[points.dtype], steps
-    r.host_policy, r.agent_policy, r.stages, r.flags = host_policy, agent_policy, stages, flags
+    r.host_policy, r.agent_policy, r.stages, r.flags = host_policy, agent_policy, stages, flags | _forced_flags
     ws = workspace if defer_counts else _workspace(dev, lib().hk_rollout_workspace_bytes(C.byref(r)))
     r.workspace, r.workspace_bytes = ws.data_ptr(), ws.numel()
     with torch.cuda.device(dev):

@@ -81,7 +81,8 @@ def main():
         b = int(rng.choice([1, 15, 16, 17, 63, 64, 65, 200, 1000, 3000]))
         sem = ["jax", "torch", "list"][rng.integers(0, 3)]
         pad = float(rng.choice([-1.0, -1.0, -1.0, -1e-8, -2.5]))
-        force = int(rng.choice([0, 0, A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC]))
+        force = int(rng.choice([0, 0, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_TEAM,
+                               A.HK_FLAG_FORCE_GENERIC]))
         noop, ign = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
         if rng.integers(0, 4) == 0:  # the flag sets of the compiled rollout configurations
             noop = ign = (sem == "torch")

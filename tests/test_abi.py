@@ -93,7 +93,7 @@ def test_rollout_and_search_validation_without_gpu():
     buf = (ctypes.c_uint8 * 64)()
     r.points = ctypes.addressof(buf)
     need = L.hk_rollout_workspace_bytes(ctypes.byref(r))
-    assert need == 1 * 6 * 4                                             # one workgroup x (steps + 1) counters
+    assert need == 4 * 6 * 4   # (steps + 1) rows of counters, one slot per 16 games: the finest kernel variant's grid
     r.flags = A.HK_FLAG_DEFER_COUNTS
     assert L.hk_rollout(ctypes.byref(r), None) == A.HK_ERR_NULL          # deferred counts need the workspace
     t = A.hk_search_tree()

@@ -237,7 +237,9 @@ def test_random_vs_oracle_fast_specs(spec):
     m, d = spec
     assert ops.has_fast_path(m, d)
     rng = np.random.default_rng(100 * m + d)
-    _check_all_ops(rng, m, d, np.float32, force_generic=False, b=97 if m < 50 else 70)
+    _check_all_ops(rng, m, d, np.float32, force_generic=False, b=97 if m < 50 else 70)  # two lanes per game
+    with ops.forced(A.HK_FLAG_FORCE_ONE_LANE):
+        _check_all_ops(rng, m, d, np.float32, force_generic=False, b=97 if m < 50 else 70)
 
 
 @pytest.mark.parametrize("spec", [(20, 3), (10, 3), (8, 4), (4, 3)])
@@ -389,11 +391,13 @@ def test_compiled_rollout_configurations_match_oracle(spec):
         for T in (1, 20):
             want_p, want = CO.rollout(p0, T, 31, game_offset=5, host_policy=A.HK_HOST_RANDOM, agent_policy=ap,
                                       stages=stages, flags=flags_o, record=False)
-            P = dev(p0.copy())
-            got = ops.rollout(P, T, 31, game_offset=5, host_policy=A.HK_HOST_RANDOM, agent_policy=ap, stages=stages,
-                              flags=flags_p)
-            assert np.array_equal(host(P), want_p), (flags_p, T)
-            assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"]), (flags_p, T)
+            for lanes in (0, A.HK_FLAG_FORCE_ONE_LANE):  # hk::duo_kernel / hk::fast_kernel (where both exist)
+                P = dev(p0.copy())
+                got = ops.rollout(P, T, 31, game_offset=5, host_policy=A.HK_HOST_RANDOM, agent_policy=ap,
+                                  stages=stages, flags=flags_p | lanes, record=("game_length",))
+                assert np.array_equal(host(P), want_p), (flags_p, T, lanes)
+                assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"]), (flags_p, T)
+                assert np.array_equal(host(got["game_length"]), want["game_length"]), (flags_p, T, lanes)
 
 
 def test_rollout_equals_stepwise_launches():
@@ -473,8 +477,13 @@ def test_baseline_sizes(b, m, d):
     assert torch.equal(res["done"], ops.get_dones(Q))
     assert bool((res["num_points"] >= 1).all())                   # a game never loses its last point
     assert bool((res["reward"] == (res["done"] & ~res["prev_done"]).float()).all())
-    # the specialised and the generic kernels agree on every game
+    # the specialised (two lanes per game / one lane per game) and the generic kernels agree on every game
     assert torch.equal(Q, ops.step(P, cls, ax, stages=7, flags=A.HK_FLAG_FORCE_GENERIC)["points"])
+    assert torch.equal(Q, ops.step(P, cls, ax, stages=7, flags=A.HK_FLAG_FORCE_ONE_LANE)["points"])
+    R1, R2 = P.clone(), P.clone()
+    c1 = ops.rollout(R1, 20, 3)["done_count"]
+    c2 = ops.rollout(R2, 20, 3, flags=A.HK_FLAG_FORCE_ONE_LANE)["done_count"]
+    assert torch.equal(R1, R2) and torch.equal(c1, c2)
     # fused rollout: monotone done counts, every game that ends stays ended
     rec = ops.rollout(P, 20, 1, record=("game_length",))
     dc = host(rec["done_count"])
