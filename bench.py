@@ -10,7 +10,7 @@ One "step" = one pass of the hot path over the whole per-GPU batch: host subset 
 shift -> reposition -> Newton polytope -> done/reward for every one of the 65 536 games, finished
 games included (the reference steps them too).  The timed region runs EXACTLY K such steps as
 K//20 episodes of 20 steps (+ one shorter episode of K%20 steps); an episode is ONE launch of the
-fused rollout kernel hk::fast_kernel<20,3,rollout> (SURVEY.md section 7 stage 5): the state is
+fused rollout kernel hk::duo_kernel<20,3,rollout> (two lanes per game; SURVEY.md section 7 stage 5): the state is
 read from HBM once, stays in registers for the 20 steps and is written back once.  Every episode
 restarts from the resident fresh states (the kernel reads them and writes the working state: no
 copy) and is followed by the reduction of the per-step finished-game counts (second tiny kernel).
@@ -254,7 +254,7 @@ def main():
                   "steps": n_ep * EPISODE,
                   "algorithmic_GBps": b * algorithmic_bytes_per_step(m, d) / step_s / 1e9,
                   "frac_of_hbm_peak": b * algorithmic_bytes_per_step(m, d) / step_s / 1e9 / HBM_PEAK_GBS,
-                  "note": "one launch of hk::fast_kernel<20,3,rollout> (T=1) + counter reduce per env step; "
+                  "note": "one launch of hk::duo_kernel<20,3,rollout> (T=1) + counter reduce per env step; "
                           "state read from and written to HBM every step"}
 
     def time_boundary_steps(start, n_ep):
@@ -325,7 +325,7 @@ def main():
                "steps": max(1, min(n_full, 50)) * EPISODE, "algorithmic_GBps": gbps,
                "frac_of_hbm_peak": gbps / HBM_PEAK_GBS, "device_copy_GBps": copy_gbps, "frac_of_device_copy": gbps / copy_gbps,
                "state_copy_us": same_us,
-               "note": "one hk_step launch per env step (hk::fast_kernel<20,3,step>): f32 state + f32 [B,d] mask "
+               "note": "one hk_step launch per env step (hk::duo_kernel<20,3,step>): f32 state + f32 [B,d] mask "
                        "+ i32 axis read from HBM, state + done + reward written back; device_copy_GBps = a 1 GiB "
                        "device-to-device copy, state_copy_us = a copy kernel over one state batch (the same bytes as "
                        "one hk_step without the actions and outcomes)"}
@@ -497,7 +497,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": f"hk::fast_kernel<{m},{d},rollout> ({b} games x {EPISODE} steps per launch)",
+                "kernel": f"hk::duo_kernel<{m},{d},rollout,jax> ({b} games x {EPISODE} steps per launch, two lanes per game)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

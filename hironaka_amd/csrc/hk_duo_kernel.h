@@ -281,6 +281,28 @@ struct DuoStagesFor {
   }
 };
 
+// The policy stream of a pair: Philox block b (steps 2b, 2b + 1) is computed by the lane with (b & 1) == h only
+// -- one Philox per lane per FOUR steps -- and its two words reach the partner through DPP.
+struct DuoPolicyCache {
+  U4 r;
+  uint32_t pair = 0xFFFFFFFFu;  // wave-uniform: `r` is block 2 * pair + h
+};
+
+__device__ inline void duo_policy_words(uint64_t gg, uint32_t step, uint64_t seed, DuoPolicyCache& cache, int h,
+                                        uint32_t& host_word, uint32_t& agent_word) {
+  const uint32_t block = step >> 1, pair = block >> 1;
+  if (cache.pair != pair) {
+    cache.r = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), (pair << 1) | (uint32_t)h, kStreamPolicy, seed);
+    cache.pair = pair;
+  }
+  const uint32_t a = (step & 1u) ? cache.r.z : cache.r.x;
+  const uint32_t b = (step & 1u) ? cache.r.w : cache.r.y;
+  const bool own = (int)(block & 1u) == h;
+  const uint32_t oa = (uint32_t)duo_other_i((int)a), ob = (uint32_t)duo_other_i((int)b);
+  host_word = own ? a : oa;
+  agent_word = own ? b : ob;
+}
+
 // ---- the kernel: fused rollouts without records (MODE kModeRollout) and single steps with the caller's actions
 // (kModeStep: hk_step) ---------------------------------------------------------------------------------------
 template <int M, int D, int MODE, int HOT = kHotNone>
@@ -309,7 +331,8 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   const unsigned stages = HOT ? (unsigned)(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON) : prm.stages;
   const float fill = ((flags & HK_SEM_MASK) == HK_SEM_JAX) ? -1.0f : pad;
   const int nsteps = kRoll ? prm.steps : 1;
-  PolicyCache pcache;
+  PolicyCache pcache;      // slow path (one lane per game computes)
+  DuoPolicyCache dcache;
   float c[D];
   int axis_in = -1;
 #pragma unroll
@@ -405,8 +428,9 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   for (int t = 0; t < nsteps; ++t) {
     int axis = axis_in, cls = 0;
     if (kRoll) {
-      uint32_t mask;
-      fast_policy<D>(seed, host_policy, agent_policy, gg, step0 + (uint32_t)t, pcache, cls, axis, mask, 0);
+      uint32_t mask, ra, rb;
+      duo_policy_words(gg, step0 + (uint32_t)t, seed, dcache, h, ra, rb);
+      policy_from_words<D>(ra, rb, host_policy, agent_policy, cls, axis, mask, 0);
 #pragma unroll
       for (int k = 0; k < D; ++k) c[k] = (float)((mask >> k) & 1u);
     }

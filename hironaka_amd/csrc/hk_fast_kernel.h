@@ -278,12 +278,9 @@ __device__ inline void fast_decode_actions(const Params& prm, const RawActions<D
 // `zeillinger_cls`: the class Zeillinger's host picks on the current state (computed by the caller, who holds
 // the rows), used when host_policy == HK_HOST_ZEILLINGER
 template <int D>
-__device__ inline void fast_policy(uint64_t seed, int host_policy, int agent_policy, uint64_t gg, uint32_t step,
-                                   PolicyCache& cache, int& cls, int& axis, uint32_t& mask,
-                                   int zeillinger_cls = 0) {
+__device__ inline void policy_from_words(uint32_t ra, uint32_t rb, int host_policy, int agent_policy, int& cls,
+                                         int& axis, uint32_t& mask, int zeillinger_cls = 0) {
   constexpr uint32_t ncls = (1u << D) - (uint32_t)D - 1u;
-  uint32_t ra, rb;
-  policy_words(gg, step, seed, cache, ra, rb);
   cls = (host_policy == HK_HOST_RANDOM) ? (int)mulhi32(ra, ncls)
                                         : (host_policy == HK_HOST_ZEILLINGER ? zeillinger_cls : (int)ncls - 1);
   mask = decode_class(cls, D);
@@ -304,6 +301,15 @@ __device__ inline void fast_policy(uint64_t seed, int host_policy, int agent_pol
   } else {
     axis = 31 - __clz(mask);
   }
+}
+
+template <int D>
+__device__ inline void fast_policy(uint64_t seed, int host_policy, int agent_policy, uint64_t gg, uint32_t step,
+                                   PolicyCache& cache, int& cls, int& axis, uint32_t& mask,
+                                   int zeillinger_cls = 0) {
+  uint32_t ra, rb;
+  policy_words(gg, step, seed, cache, ra, rb);
+  policy_from_words<D>(ra, rb, host_policy, agent_policy, cls, axis, mask, zeillinger_cls);
 }
 
 template <int D>

@@ -18,8 +18,9 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-HEADLINE_GRID = "65536"  # 1024 waves x 64 lanes = 65 536 games (BASELINE configs[1])
-HEADLINE_KERNEL = re.compile(r"fast_kernel<20, 3, 1, (1|true)>")  # hk::fast_kernel<20,3,rollout,kHotJax>
+HEADLINE_GRID = "131072"  # 2048 waves x 64 lanes = 65 536 games, two lanes each (BASELINE configs[1])
+HEADLINE_KERNEL = re.compile(r"duo_kernel<20, 3, 1, 1>")  # hk::duo_kernel<20,3,rollout,kHotJax>
+STEP_KERNEL = re.compile(r"duo_kernel<20, 3, 0, 0>")      # hk::duo_kernel<20,3,step> (hk_step)
 
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
@@ -46,7 +47,7 @@ if trace:
     lines.append("kernel,grid_threads,calls,mean_us,p50_us,p95_us")
     for (k, grid), v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
         v = np.array(v)
-        if "fast_kernel<" in k and k.split("<")[1].split(",")[2].strip(" >") == "1":  # rollout mode
+        if ("fast_kernel<" in k or "duo_kernel<" in k) and k.split("<")[1].split(",")[2].strip(" >") == "1":  # rollout mode
             big, small = split_rollout(v)
             parts = (("T=20 episodes", big), ("T=1 steps", small))
         else:
@@ -60,8 +61,8 @@ if trace:
     open(os.path.join(dst, f"{tag}_kernel_durations.csv"), "w").write("\n".join(lines) + "\n")
 
 pmc_rows = ["# rocprofv3 --pmc passes (own runs, --kernel-trace only) of bench.py --steps 2000; means per dispatch at",
-            "# the headline launch shape (1024 waves x 64 games): rollout = hk::fast_kernel<20,3,rollout> with 20 steps",
-            "# (T20) or one step (T1) per launch, step = hk::fast_kernel<20,3,step> (hk_step).  FETCH_SIZE / WRITE_SIZE in",
+            "# the headline launch shape (2048 waves x 32 games): rollout = hk::duo_kernel<20,3,rollout,jax> with 20 steps",
+            "# (T20) or one step (T1) per launch, step = hk::duo_kernel<20,3,step> (hk_step).  FETCH_SIZE / WRITE_SIZE in",
             "# KiB; on gfx950 FETCH_SIZE tallies 64 B per 128-B request: read bytes = 2 x FETCH_SIZE KiB",
             "# (MI355X_MICROARCH.md, HBM).",
             "counter,rollout_T20,rollout_T20_per_wave,rollout_T1,rollout_T1_per_wave,step,step_per_wave"]
@@ -79,7 +80,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
             continue
         if HEADLINE_KERNEL.search(r["Kernel_Name"]):  # the JAX-configuration rollout kernel only
             e = roll[r["Dispatch_Id"]]
-        elif "fast_kernel<20, 3, 0" in r["Kernel_Name"]:
+        elif STEP_KERNEL.search(r["Kernel_Name"]):
             e = step[r["Dispatch_Id"]]
         else:
             continue
@@ -95,7 +96,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     mean = lambda rows, k: float(np.mean([e[k] for e in rows])) if rows else float("nan")
     for k in sorted(L[0]):
         a, b, c = mean(L, k), mean(S, k), mean(P, k)
-        pmc_rows.append(f"{k},{a:.6g},{a/1024:.6g},{b:.6g},{b/1024:.6g},{c:.6g},{c/1024:.6g}")
+        pmc_rows.append(f"{k},{a:.6g},{a/2048:.6g},{b:.6g},{b/2048:.6g},{c:.6g},{c/2048:.6g}")
         if k in ("FETCH_SIZE", "WRITE_SIZE"):
             traffic[k] = {"T20_KiB": a, "T1_KiB": b, "step_KiB": c}
 open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w").write("\n".join(pmc_rows) + "\n")
