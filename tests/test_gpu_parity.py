@@ -521,7 +521,7 @@ def test_error_behaviour():
 def test_ragged_batch_sizes(b):
     """batches that do not fill the last wave (or even one wave), every kernel family, step + rollout +
     generate; also checks nothing is written past the batch (guard rows after the tensors)."""
-    for (m, d), flag_sets in (((20, 3), (0, A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC)),
+    for (m, d), flag_sets in (((20, 3), (0, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC)),
                               ((50, 4), (0, A.HK_FLAG_FORCE_GENERIC)), ((7, 5), (0, A.HK_FLAG_FORCE_GENERIC))):
         p0 = CO.generate_points(b, m, d, 20, 3, game_offset=9)
         rng = np.random.default_rng(b)
@@ -543,6 +543,11 @@ def test_ragged_batch_sizes(b):
             assert np.array_equal(host(rec["axis"]), want_rec["axis"])
             assert np.array_equal(host(rec["game_length"]), want_rec["game_length"])
             assert np.array_equal(host(rec["done_count"]).astype(np.uint64), want_rec["done_count"])
+            plain = guard.clone()  # without per-step records: the plain rollout kernels (two lanes / one lane)
+            prec = ops.rollout(plain[:b], 5, 11, game_offset=9, flags=fl, record=("game_length",))
+            assert np.array_equal(host(plain[:b]), want_roll) and bool((plain[b:] == 123.0).all()), (m, d, fl)
+            assert np.array_equal(host(prec["game_length"]), want_rec["game_length"])
+            assert np.array_equal(host(prec["done_count"]).astype(np.uint64), want_rec["done_count"])
             gen = torch.full((b + 1, m, d), 7.0, device="cuda")
             ops.generate_points(b, m, d, 20, seed=3, game_offset=9, flags=fl, out=gen[:b])
             assert np.array_equal(host(gen[:b]), p0) and bool((gen[b:] == 7.0).all())
