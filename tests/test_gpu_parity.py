@@ -627,6 +627,20 @@ def test_deferred_counts_equal_per_launch_counts(spec):
     assert torch.equal(got, want)
     with pytest.raises(ValueError):
         ops.rollout(P.clone(), T, 1, defer_counts=True)
+    # launches served by different kernel variants (two lanes / one lane per game, team, Zeillinger's host, and
+    # a recording rollout) meet in ONE workspace: its rows have the same length for all of them
+    variants = [dict(), dict(flags=A.HK_FLAG_FORCE_ONE_LANE), dict(flags=A.HK_FLAG_FORCE_TEAM),
+                dict(host_policy=A.HK_HOST_ZEILLINGER), dict(record=("axis",))]
+    if d > 6:
+        variants = [dict(), dict(host_policy=A.HK_HOST_ZEILLINGER), dict(record=("axis",))]
+    want = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+    for kw in variants:
+        want += ops.rollout(P.clone(), T, 7, **kw)["done_count"]
+    for kw in variants:
+        ops.rollout(P.clone(), T, 7, defer_counts=True, workspace=ws, **kw)
+    got.zero_()
+    ops.reduce_counts(ws, got, b, T, spec)
+    assert torch.equal(got, want) and int(ws.sum()) == 0
 
 
 @pytest.mark.parametrize("spec", [(20, 3), (10, 3), (8, 4), (4, 3), (50, 4), (33, 4), (64, 3), (12, 6), (7, 3), (9, 7)])
