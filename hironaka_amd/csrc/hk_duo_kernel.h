@@ -77,35 +77,40 @@ __device__ __forceinline__ void duo_slab_commit(DuoSlabRegs<M, D>& r, float* lds
   }
 }
 
-template <int M, int D, bool CONTIG>
+// kBatch: image chunks read per round (everything at once for the final store; fewer inside the recording loop,
+// whose register budget the rows own)
+template <int M, int D, bool CONTIG, int kBatch>
 __device__ __forceinline__ void duo_store_slab_impl(const float* lds, float* base, int64_t out_stride, int ngames,
                                                     int lane) {
   using G = FastGeom<M, D>;
   using V = typename VecOf<G::W>::type;
   constexpr int QH = DuoGeom<M, D>::QH;
   const int total = ngames * G::Q;
-  V v[QH];
 #pragma unroll
-  for (int it = 0; it < QH; ++it) {  // the image holds kDuoGames games whatever ngames is
-    int q = lane + it * kWave;
-    q = q < kDuoGames * G::Q ? q : kDuoGames * G::Q - 1;
-    v[it] = *reinterpret_cast<const V*>(lds + slab_chunk_lds<M, D>(q));
-  }
+  for (int i0 = 0; i0 < QH; i0 += kBatch) {
+    V v[kBatch];
 #pragma unroll
-  for (int it = 0; it < QH; ++it) asm volatile("" : "+v"(v[it]));
+    for (int u = 0; u < kBatch; ++u) {  // the image holds kDuoGames games whatever ngames is
+      int q = lane + (i0 + u) * kWave;
+      q = q < kDuoGames * G::Q ? q : kDuoGames * G::Q - 1;
+      v[u] = *reinterpret_cast<const V*>(lds + slab_chunk_lds<M, D>(q));
+    }
 #pragma unroll
-  for (int it = 0; it < QH; ++it) {
-    const int q = lane + it * kWave;
-    if (q < total) *reinterpret_cast<V*>(base + slab_chunk_global<M, D, CONTIG>(q, out_stride)) = v[it];
+    for (int u = 0; u < kBatch; ++u) asm volatile("" : "+v"(v[u]));
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const int q = lane + (i0 + u) * kWave;
+      if (i0 + u < QH && q < total) *reinterpret_cast<V*>(base + slab_chunk_global<M, D, CONTIG>(q, out_stride)) = v[u];
+    }
   }
 }
 
-template <int M, int D>
+template <int M, int D, int kBatch = DuoGeom<M, D>::QH>
 __device__ inline void duo_store_slab(const float* lds, float* out, int64_t out_stride, int64_t g0, int ngames,
                                       int lane) {
   float* base = out + g0 * out_stride;
-  if (out_stride == FastGeom<M, D>::N) duo_store_slab_impl<M, D, true>(lds, base, out_stride, ngames, lane);
-  else duo_store_slab_impl<M, D, false>(lds, base, out_stride, ngames, lane);
+  if (out_stride == FastGeom<M, D>::N) duo_store_slab_impl<M, D, true, kBatch>(lds, base, out_stride, ngames, lane);
+  else duo_store_slab_impl<M, D, false, kBatch>(lds, base, out_stride, ngames, lane);
 }
 
 // ---- image <-> registers ----------------------------------------------------------------------------------
@@ -303,12 +308,13 @@ __device__ inline void duo_policy_words(uint64_t gg, uint32_t step, uint64_t see
   agent_word = own ? b : ob;
 }
 
-// ---- the kernel: fused rollouts without records (MODE kModeRollout) and single steps with the caller's actions
-// (kModeStep: hk_step) ---------------------------------------------------------------------------------------
+// ---- the kernel: fused rollouts (MODE kModeRollout; kModeRolloutRec: with per-step observations / records) and
+// single steps with the caller's actions (kModeStep: hk_step) -------------------------------------------------
 template <int M, int D, int MODE, int HOT = kHotNone>
 __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t in_stride0, int batch0,
                                                        const Params prm) {
-  constexpr bool kRoll = MODE == kModeRollout;
+  constexpr bool kRec = MODE == kModeRolloutRec;
+  constexpr bool kRoll = MODE == kModeRollout || kRec;
   using G = FastGeom<M, D>;
   constexpr int CH = DuoGeom<M, D>::CH;
   static_assert(M <= 32, "the live mask of a game travels as 32 bits");
@@ -368,6 +374,11 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
     }
     for (int t = 0; t < nsteps; ++t) {
       int axis = axis_in, cls = 0;
+      if (kRec && prm.obs_out) {
+        __syncthreads();
+        duo_store_slab<M, D, 2>(lds, (float*)prm.obs_out + (int64_t)t * prm.batch * G::N, (int64_t)G::N, g0, ngames, lane);
+        __syncthreads();
+      }
       if (kRoll) {
         uint32_t mask;
         const int zc = (prm.host_policy == HK_HOST_ZEILLINGER && leader) ? zeillinger_game<float>(mine, prm.m, prm.d) : 0;
@@ -387,6 +398,13 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
       if (kRoll && prm.count_ws) {
         const unsigned long long bd = __ballot(leader && done);
         if (lane == 0) count_add(prm.count_ws + (size_t)(t + 1) * prm.count_stride + blockIdx.x, (uint32_t)__popcll(bd));
+      }
+      if (kRec && leader) {
+        const int64_t at = (int64_t)t * prm.batch + g;
+        if (prm.r_host_class_out) prm.r_host_class_out[at] = cls;
+        if (prm.r_axis_out) prm.r_axis_out[at] = axis;
+        if (prm.r_done_out) prm.r_done_out[at] = done;
+        if (prm.r_reward_out) prm.r_reward_out[at] = prm.reward_sign * (float)(done && !prev_done);
       }
       if (!kRoll && leader) {
         if (prm.done_out) prm.done_out[g] = done;
@@ -425,8 +443,18 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   else
     asm volatile("" : "+s"(count_slot), "+s"(count_stride), "+s"(step0), "+s"(seed), "+s"(host_policy),
                  "+s"(agent_policy));
+  const bool want_obs = kRec && prm.obs_out != nullptr;
+  const bool want_records = kRec && (prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out);
   for (int t = 0; t < nsteps; ++t) {
     int axis = axis_in, cls = 0;
+    if (want_obs) {  // state before the step: rebuild the image, store it coalesced
+      __syncthreads();
+      if (h == 0) fill_image<M, D>(mine, pad);
+      __syncthreads();
+      duo_scatter<M, CH, D>(q, mine, gmask, smax, h);
+      __syncthreads();
+      duo_store_slab<M, D, 2>(lds, (float*)prm.obs_out + (int64_t)t * prm.batch * G::N, (int64_t)G::N, g0, ngames, lane);
+    }
     if (kRoll) {
       uint32_t mask, ra, rb;
       duo_policy_words(gg, step0 + (uint32_t)t, seed, dcache, h, ra, rb);
@@ -444,6 +472,13 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
       if (prm.prev_done_out) prm.prev_done_out[g] = prev_done;
       if (prm.reward_out) prm.reward_out[g] = prm.reward_sign * (float)(done && !prev_done);
       if (prm.num_points_out) prm.num_points_out[g] = np;
+    }
+    if (want_records && leader) {
+      const int64_t at = (int64_t)t * prm.batch + g;
+      if (prm.r_host_class_out) prm.r_host_class_out[at] = cls;
+      if (prm.r_axis_out) prm.r_axis_out[at] = axis;
+      if (prm.r_done_out) prm.r_done_out[at] = done;
+      if (prm.r_reward_out) prm.r_reward_out[at] = prm.reward_sign * (float)(done && !prev_done);
     }
     if (count_slot) {
       const unsigned long long bd = __ballot(leader && done);
@@ -481,7 +516,6 @@ inline bool duo_wanted(const Params& prm) {
   }();
   if ((prm.mode != kModeRollout && prm.mode != kModeStep) || prm.m > 32) return false;
   if (prm.mode == kModeStep && (prm.class_out || (prm.stages & kStageFeatureSorts))) return false;
-  if (prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out) return false;
   if (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER) return false;
   if ((prm.stages & HK_STAGE_NEWTON) &&
       ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)))
@@ -497,8 +531,12 @@ int launch_duo_t(Params prm, hipStream_t stream) {
   const unsigned grid = (unsigned)(((int64_t)prm.batch + kDuoGames - 1) / kDuoGames);
   prm.games_per_block = kDuoGames;
   launch_prepare();
-  const int hot = prm.mode == kModeRollout ? fast_hot_config(prm) : kHotNone;
-  if (prm.mode == kModeStep)
+  const bool records = prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out;
+  const int hot = (prm.mode == kModeRollout && !records) ? fast_hot_config(prm) : kHotNone;
+  if (prm.mode == kModeRollout && records)
+    hipLaunchKernelGGL((duo_kernel<M, D, kModeRolloutRec>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
+                       prm.in_stride, prm.batch, prm);
+  else if (prm.mode == kModeStep)
     hipLaunchKernelGGL((duo_kernel<M, D, kModeStep>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
                        prm.in_stride, prm.batch, prm);
   else if (hot == kHotJax)
