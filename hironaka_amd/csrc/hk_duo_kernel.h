@@ -1,4 +1,4 @@
-// Two lanes per game: the rollout kernel for batches that do not fill the device.
+// Two lanes per game: steps and rollouts for batches that do not fill the device.
 //
 // hk::fast_kernel holds a game in ONE lane, so 65 536 games are 1024 instruction streams for the 1024 SIMDs of
 // an MI355X, and a lone wave per SIMD issues an instruction only every ~7.7 cycles: the
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------
-// rollouts without records on a shape with a register-resident specialisation, when the batch leaves SIMDs
+// steps and rollouts on a shape with a register-resident specialisation, when the batch leaves SIMDs
 // short of a second wave under the one-lane kernel
 inline bool duo_wanted(const Params& prm) {
   static const int forced = [] {  // tuning hook (scripts/probe_variants.py): HK_DUO=0|1 overrides the heuristic
