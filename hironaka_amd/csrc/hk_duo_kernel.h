@@ -536,6 +536,11 @@ int launch_duo_t(Params prm, hipStream_t stream) {
   if (prm.mode == kModeRollout && records)
     hipLaunchKernelGGL((duo_kernel<M, D, kModeRolloutRec>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
                        prm.in_stride, prm.batch, prm);
+  else if (prm.mode == kModeStep && prm.flags == HK_SEM_JAX &&
+           prm.stages == (HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON))
+    // take_actions as the JAX trainer configures it (jax/util.py:83-125 with reposition, without rescale)
+    hipLaunchKernelGGL((duo_kernel<M, D, kModeStep, kHotJax>), dim3(grid), dim3(kWave), 0, stream,
+                       (const float*)prm.in, prm.in_stride, prm.batch, prm);
   else if (prm.mode == kModeStep)
     hipLaunchKernelGGL((duo_kernel<M, D, kModeStep>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
                        prm.in_stride, prm.batch, prm);
