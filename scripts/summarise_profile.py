@@ -20,7 +20,7 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 HEADLINE_GRID = "131072"  # 2048 waves x 64 lanes = 65 536 games, two lanes each (BASELINE configs[1])
 HEADLINE_KERNEL = re.compile(r"duo_kernel<20, 3, 1, 1>")  # hk::duo_kernel<20,3,rollout,kHotJax>
-STEP_KERNEL = re.compile(r"duo_kernel<20, 3, 0, 0>")      # hk::duo_kernel<20,3,step> (hk_step)
+STEP_KERNEL = re.compile(r"duo_kernel<20, 3, 0, 1>")      # hk::duo_kernel<20,3,step,jax> (hk_step as bench.py calls it)
 
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
