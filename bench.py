@@ -325,7 +325,7 @@ def main():
                "steps": max(1, min(n_full, 50)) * EPISODE, "algorithmic_GBps": gbps,
                "frac_of_hbm_peak": gbps / HBM_PEAK_GBS, "device_copy_GBps": copy_gbps, "frac_of_device_copy": gbps / copy_gbps,
                "state_copy_us": same_us,
-               "note": "one hk_step launch per env step (hk::duo_kernel<20,3,step>): f32 state + f32 [B,d] mask "
+               "note": "one hk_step launch per env step (hk::duo_kernel<20,3,step,jax>): f32 state + f32 [B,d] mask "
                        "+ i32 axis read from HBM, state + done + reward written back; device_copy_GBps = a 1 GiB "
                        "device-to-device copy, state_copy_us = a copy kernel over one state batch (the same bytes as "
                        "one hk_step without the actions and outcomes)"}
