@@ -62,16 +62,17 @@ int launch_generic(Params& prm, int dtype, hipStream_t stream) {
 // kernel selection: register-resident specialisation -> team kernel (f32, dim 2..6, <= 64 rows; also the
 // specialised shapes on HK_FLAG_FORCE_TEAM) -> generic kernel (anything else: f64, dim > 6, > 64 rows,
 // HK_FLAG_FORCE_GENERIC, and the few mode / semantics combinations fast_supported / team_supported decline)
+constexpr unsigned kHostSideFlags = HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES;  // kernel selection only
 static bool use_duo(const Params& prm) { return !(prm.flags & HK_FLAG_FORCE_ONE_LANE) && duo_wanted(prm); }
 
 int launch(Params& prm, int dtype, hipStream_t stream) {
   if (prm.batch == 0) return HK_OK;
   if (fast_supported(prm, dtype)) {
     const bool duo = use_duo(prm);
-    prm.flags &= ~HK_FLAG_FORCE_ONE_LANE;  // host-side only (the compiled rollout configurations compare flags)
+    prm.flags &= ~kHostSideFlags;  // (the compiled rollout configurations compare flags)
     return duo ? launch_duo(prm, stream) : launch_fast(prm, stream);
   }
-  prm.flags &= ~HK_FLAG_FORCE_ONE_LANE;
+  prm.flags &= ~kHostSideFlags;
   if (team_supported(prm, dtype)) {
     const int st = launch_team(prm, stream);
     if (st != HK_ERR_UNSUPPORTED) return st;
@@ -120,7 +121,9 @@ size_t coords_align(int kind) {
   }
 }
 
-int params_from_step(const hk_step_desc* s, Params& prm) {
+// `internal_stages`: the feature-sort bits hk_get_features / hk_get_features_torch add on top of the public
+// stage mask (callers of hk_step cannot set them: they are not in include/hironaka_hip.h)
+int params_from_step(const hk_step_desc* s, Params& prm, unsigned internal_stages = 0) {
   if (!s) return HK_ERR_NULL;
   int st = check_spec(s->batch, s->max_points, s->dim, s->dtype);
   if (st != HK_OK) return st;
@@ -130,7 +133,7 @@ int params_from_step(const hk_step_desc* s, Params& prm) {
   if (s->in_stride < n || s->out_stride < n) return HK_ERR_SHAPE;
   const size_t es = elem_size(s->dtype);
   if (!aligned(s->points_in, es) || !aligned(s->points_out, es)) return HK_ERR_ALIGN;
-  if (s->stages & ~(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON | HK_STAGE_RESCALE | kStageFeatureSorts))
+  if (s->stages & ~(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON | HK_STAGE_RESCALE))
     return HK_ERR_UNSUPPORTED;
   if ((s->flags & HK_SEM_MASK) == HK_SEM_MASK) return HK_ERR_UNSUPPORTED;
   prm = Params{};
@@ -169,7 +172,7 @@ int params_from_step(const hk_step_desc* s, Params& prm) {
   prm.batch = s->batch;
   prm.m = s->max_points;
   prm.d = s->dim;
-  prm.stages = s->stages;
+  prm.stages = s->stages | (internal_stages & kStageFeatureSorts);
   prm.flags = s->flags;
   prm.mode = kModeStep;
   return HK_OK;
@@ -498,11 +501,11 @@ int hk_get_features(const void* points_in, int64_t in_stride, void* features_out
                     int64_t out_stride, int batch, int max_points, int dim, int dtype,
                     int scale_observation, double padding_value, void* stream) {
   hk_step_desc s = plain_desc(points_in, features_out, batch, max_points, dim, dtype, padding_value,
-                              (scale_observation ? HK_STAGE_RESCALE : 0u) | kStageFeatureSort, HK_SEM_JAX);
+                              (scale_observation ? HK_STAGE_RESCALE : 0u), HK_SEM_JAX);
   s.in_stride = in_stride;
   s.out_stride = out_stride;
   Params prm{};
-  const int st = params_from_step(&s, prm);
+  const int st = params_from_step(&s, prm, kStageFeatureSort);
   if (st != HK_OK) return st;
   return launch(prm, dtype, (hipStream_t)stream);
 }
@@ -510,11 +513,11 @@ int hk_get_features(const void* points_in, int64_t in_stride, void* features_out
 int hk_get_features_torch(const void* points_in, int64_t in_stride, void* features_out, int64_t out_stride,
                           int batch, int max_points, int dim, int dtype, double padding_value, void* stream) {
   hk_step_desc s = plain_desc(points_in, features_out, batch, max_points, dim, dtype, padding_value,
-                              kStageFeatureSort0, HK_SEM_TORCH);
+                              0u, HK_SEM_TORCH);
   s.in_stride = in_stride;
   s.out_stride = out_stride;
   Params prm{};
-  const int st = params_from_step(&s, prm);
+  const int st = params_from_step(&s, prm, kStageFeatureSort0);
   if (st != HK_OK) return st;
   return launch(prm, dtype, (hipStream_t)stream);
 }

@@ -509,21 +509,32 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
 // ---- host side -----------------------------------------------------------------------------------------------
 // steps and rollouts on a shape with a register-resident specialisation, when the batch leaves SIMDs
 // short of a second wave under the one-lane kernel
+// SIMDs of the current device (4 per CU); queried once per device
+inline int device_simds() {
+  static int cached[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  if (!cached[dev]) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    (void)hipGetLastError();
+    cached[dev] = 4 * cus;
+  }
+  return cached[dev];
+}
+
 inline bool duo_wanted(const Params& prm) {
-  static const int forced = [] {  // tuning hook (scripts/probe_variants.py): HK_DUO=0|1 overrides the heuristic
-    const char* e = getenv("HK_DUO");
-    return e ? atoi(e) : -1;
-  }();
   if ((prm.mode != kModeRollout && prm.mode != kModeStep) || prm.m > 32) return false;
   if (prm.mode == kModeStep && (prm.class_out || (prm.stages & kStageFeatureSorts))) return false;
   if (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER) return false;
   if ((prm.stages & HK_STAGE_NEWTON) &&
       ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)))
     return false;
-  if (forced >= 0) return forced != 0;
-  // measured (scripts/probe_duo.py): ahead while the one-lane kernel leaves SIMDs short of a second wave --
-  // up to ~65 536 games, and at any size for the shapes whose one-lane kernel runs one wave per SIMD
-  return prm.batch <= 98304 || prm.m * prm.d > 64;
+  if (prm.flags & HK_FLAG_FORCE_TWO_LANES) return true;
+  // measured (scripts/probe_duo.py): ahead while the one-lane kernel (64 games per wave) leaves SIMDs short of
+  // a second wave -- up to 1.5 waves per SIMD, 98 304 games on the 1024 SIMDs of an MI355X -- and at any size
+  // for the shapes whose one-lane kernel runs one wave per SIMD
+  return (int64_t)prm.batch * 2 <= (int64_t)3 * kWave * device_simds() || prm.m * prm.d > 64;
 }
 
 template <int M, int D>

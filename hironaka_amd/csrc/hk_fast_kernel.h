@@ -623,16 +623,7 @@ bool fast_aligned_t(const Params& prm) {
 // games.  Putting fewer games in a wave (idle lanes, more waves) does not buy that back: measured at
 // 65 536 games, 64/32/16 games per wave give 50.4/50.7/84.8 us per 20-step rollout and 11.6/12.3/18.5 us
 // per hk_step, so a wave always takes 64 games.
-inline int fast_games_per_block(const Params& prm) {
-  // tuning hook (scripts/probe_stages.py): HK_FAST_GAMES_PER_WAVE=16|32|64 overrides the heuristic
-  static const int forced = [] {
-    const char* e = getenv("HK_FAST_GAMES_PER_WAVE");
-    const int v = e ? atoi(e) : 0;
-    return (v == 16 || v == 32 || v == 64) ? v : 0;
-  }();
-  if (forced) return forced;
-  return kWave;
-}
+inline int fast_games_per_block(const Params&) { return kWave; }
 
 inline int fast_hot_config(const Params& prm) {
   if (prm.stages != (HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON) || prm.host_policy != HK_HOST_RANDOM)

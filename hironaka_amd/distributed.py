@@ -40,12 +40,22 @@ def shard_range(total_games: int, rank_: Optional[int] = None, world_: Optional[
 
 def all_gather_games(local: torch.Tensor, shard: Optional[Shard] = None) -> torch.Tensor:
     """[B_local, ...] per rank -> [B_total, ...] on every rank, in global game order.  Equal shards use
-    one all_gather_into_tensor; ragged shards are padded to the largest one first."""
+    one all_gather_into_tensor; ragged shards are padded to the largest one first.  Without a `shard` the
+    ranks first exchange their local sizes (one tiny all-gather), so ragged inputs take the padded path
+    instead of failing inside the collective."""
     w = world()
     if w == 1:
         return local
-    sizes = [shard_range(shard.total, r, w).size for r in range(w)] if shard is not None else None
-    if sizes is None or len(set(sizes)) == 1:
+    if shard is not None:
+        sizes = [shard_range(shard.total, r, w).size for r in range(w)]
+        if sizes[rank()] != local.shape[0]:
+            raise ValueError(f"rank {rank()} holds {local.shape[0]} games, its shard of {shard.total} is {sizes[rank()]}")
+    else:
+        mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+        every = torch.empty(w, dtype=torch.int64, device=local.device)
+        dist.all_gather_into_tensor(every, mine)
+        sizes = [int(v) for v in every.tolist()]
+    if len(set(sizes)) == 1:
         out = torch.empty((w * local.shape[0], *local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous())
         return out

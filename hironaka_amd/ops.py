@@ -287,9 +287,11 @@ def get_features(points: torch.Tensor, scale_observation: bool = True, padding_v
     if pts.dim() == 3:
         b, m, d = pts.shape
         in_stride = m * d
-    else:
+    elif pts.dim() == 2 and spec is not None:
         b, in_stride = pts.shape
         m, d = spec
+    else:
+        raise ValueError("points must be [B, m, d], or [B, stride] together with spec=(m, d)")
     out = torch.empty((b, m * d), dtype=pts.dtype, device=pts.device)
     with torch.cuda.device(pts.device):
         check(lib().hk_get_features(pts.data_ptr(), in_stride, out.data_ptr(), m * d, b, m, d,
@@ -335,14 +337,24 @@ def generate_points(batch: int, max_points: int, dim: int, max_value: int, seed:
 
 
 _WORKSPACES: Dict[Tuple[torch.device, int], torch.Tensor] = {}
+_RETIRED_WORKSPACES: list = []  # outgrown buffers: a hipGraph captured earlier may still hold their address
 
 
 def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
     """Per-(device, stream) memory for hk_rollout's per-workgroup counters, grown on demand (the C ABI
-    never allocates).  Zero when created; every reduction leaves it zero again."""
+    never allocates).  Zero when created; every reduction leaves it zero again.  A buffer that a larger
+    request outgrows is retired, not freed (a captured graph may replay launches that add to it), and growing
+    DURING a capture is refused: allocate first (one eager call of the same shape, or the caller's own
+    `rollout_workspace` + `defer_counts`)."""
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("hk_rollout's counter workspace would have to be (re)allocated inside a stream "
+                               "capture: run the same rollout once eagerly on this stream first, or pass "
+                               "workspace=ops.rollout_workspace(...) with defer_counts=True")
+        if ws is not None:
+            _RETIRED_WORKSPACES.append(ws)
         ws = torch.zeros(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
         _WORKSPACES[key] = ws
     return ws

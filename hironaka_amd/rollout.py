@@ -12,7 +12,8 @@
   ``(B*T, obs_dim) / (B*T, A) / (B*T,)`` for fixed policies: observations before each step, one-hot
   policy targets of the actions taken, and discounted-reward value targets (value of a finished game:
   +-discount^k to the finishing step, the convention pinned by test/testJAXTrainer.py:91-389).
-  The Gumbel-MuZero search of the reference (third-party mctx) is NOT part of this build.
+  (Rollouts WITH the Gumbel-MuZero search -- third-party mctx in the reference -- are
+  ``hironaka_amd.simulation_fn`` / ``hironaka_amd.trainer_api.HipTrainer.simulate``.)
 """
 from __future__ import annotations
 
@@ -32,8 +33,11 @@ _AGENTS = {"random": A.HK_AGENT_RANDOM, "random_legal": A.HK_AGENT_RANDOM_LEGAL,
 
 def details_from_done_counts(done_count: torch.Tensor, total_games: int) -> List[int]:
     """done_count[s] = #games finished after s steps (s = 0..L-1)  ->  the reference's `details`
-    histogram of length L (jax_trainer.py:501,525,540): details[s] = newly finished at step s for
-    s < L-1, details[L-1] = everything not finished after L-2 steps."""
+    histogram of length L, exactly as its loop leaves it (jax_trainer.py:501,519-540): details[s] =
+    done_count[s] - done_count[s-1] for s < L-1 (added at the top of loop iteration s, before that
+    iteration's move), and after the last of the L-1 moves details[L-1] = total - done_count[L-1].
+    Games that finish on the very last move are therefore in NO bin (the reference drops them: neither
+    the numerator nor the denominator of rho sees them); sum(details) <= total."""
     dc = [int(v) for v in done_count.tolist()]
     length = len(dc)
     details = [0] * length
@@ -41,7 +45,7 @@ def details_from_done_counts(done_count: torch.Tensor, total_games: int) -> List
     for s in range(length - 1):
         details[s] = dc[s] - prev
         prev = dc[s]
-    details[length - 1] = total_games - dc[length - 2] if length >= 2 else total_games
+    details[length - 1] = total_games - dc[length - 1]
     return details
 
 
@@ -57,7 +61,11 @@ def compute_rho(host: Union[str, Callable], agent: Union[str, Callable], *, spec
     """jax_trainer.py:467-556.  `host` / `agent`: a name from players.py ("random", "all_coord",
     "zeillinger" / "random", "random_legal", "choose_first", "choose_last") -> fused kernel; or
     callables host(pts_flat, key=) -> one-hot [B, A], agent(agent_obs, key=) -> one-hot [B, d].
-    `game_offset` / `world_batch` place this process' shard inside a larger sharded batch."""
+    `game_offset` / `world_batch` place this process' shard inside a larger sharded batch: when
+    `world_batch` exceeds `batch_size` (one process per GPU, torch.distributed initialised) the per-step
+    finished-game counts are summed over the ranks (`distributed.all_reduce_counts` -- the reference sums them
+    over its device axis, jax_trainer.py:513,533-534) and every rank returns the histogram of all
+    `world_batch * num_of_loops` games."""
     m, d = spec
     stages = ops.make_stages(True, reposition, True, False)
     fused = isinstance(host, str) and isinstance(agent, str)
@@ -77,7 +85,7 @@ def compute_rho(host: Union[str, Callable], agent: Union[str, Callable], *, spec
                         agent_policy=_AGENTS[agent], stages=stages, defer_counts=True, workspace=workspace)
         if workspace is not None:
             ops.reduce_counts(workspace, totals, batch_size, max_length - 1, spec, dtype)
-        details = details_from_done_counts(totals, batch_size * num_of_loops)
+        details = details_from_done_counts(_world_counts(totals, batch_size, world_batch), world_batch * num_of_loops)
         return rho_from_details(details), details
     # arbitrary callables: the reference's step-by-step loop over take_actions (one fused launch per step)
     take_action = get_take_actions("host", spec, rescale_points=False, reposition=reposition)
@@ -96,8 +104,19 @@ def compute_rho(host: Union[str, Callable], agent: Union[str, Callable], *, spec
             flat = take_action(flat, coords, axis)
             counts[step + 1] = get_dones(flat.reshape(-1, m, d)).sum()
         totals = counts.clone() if totals is None else totals + counts
-    details = details_from_done_counts(totals, batch_size * num_of_loops)
+    details = details_from_done_counts(_world_counts(totals, batch_size, world_batch), world_batch * num_of_loops)
     return rho_from_details(details), details
+
+
+def _world_counts(totals: torch.Tensor, batch_size: int, world_batch: int) -> torch.Tensor:
+    """this rank's per-step finished-game counts -> those of the whole sharded batch"""
+    if world_batch == batch_size:
+        return totals
+    from . import distributed as hkdist
+    if hkdist.world() == 1:
+        raise ValueError(f"world_batch={world_batch} != batch_size={batch_size} needs an initialised "
+                         f"torch.distributed process group (one process per GPU)")
+    return hkdist.all_reduce_counts(totals)
 
 
 def simulate_fixed_policies(key: int, role: str, *, spec: Tuple[int, int], batch_size: int, max_value: int,

@@ -33,6 +33,13 @@ def _worker(rank, world, port, total, tmpdir):
         local = CO.generate_points(shard.size, m, d, 20, 42, game_offset=shard.start)
         final, rec = CO.rollout(local, T, 7, game_offset=shard.start)
         gathered = D.all_gather_games(torch.from_numpy(final), shard)
+        # without a Shard the ranks exchange their sizes first: ragged inputs take the padded path too
+        assert torch.equal(D.all_gather_games(torch.from_numpy(final)), gathered)
+        try:
+            D.all_gather_games(torch.from_numpy(final)[:-1], shard)
+            raise AssertionError("a local batch that is not the rank's shard must be rejected")
+        except ValueError:
+            pass
         obs = D.all_gather_rollout((torch.from_numpy(rec["obs"][0]), torch.from_numpy(rec["axis"][0]),
                                     torch.from_numpy(rec["reward"][0])), shard)
         counts = D.all_reduce_counts(torch.from_numpy(rec["done_count"].astype(np.int64)))

@@ -366,7 +366,7 @@ def test_compute_rho_fused_equals_stepwise():
     rho_f, det_f = compute_rho("all_coord", "choose_first", **kw)
     rho_s, det_s = compute_rho(lambda o, **k: all_coord_host_fn(o.reshape(-1, 20, 3)),
                                lambda o, **k: choose_first_agent_fn(o, (20, 3)), **kw)
-    assert det_f == det_s and rho_f == rho_s and sum(det_f) == 4096
+    assert det_f == det_s and rho_f == rho_s and sum(det_f) <= 4096  # last-move finishers are in no bin
     rho, det = compute_rho("random", "random", **kw)
     want = np.zeros(12, dtype=np.int64)
     for loop in range(2):
