@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the batched Hironaka-game step on MI355X.
 
+    python bench.py --gpus N --steps K --warmup W
+
 Workload (BASELINE.json configs[1]): dim=3, max_points=20, batch=65 536 games per GPU, float32,
 max_value=20, reposition on / rescale off (hironaka/jax/jax_config.yml), uniformly random host
 class and agent axis sampled INSIDE the kernel (Philox), episodes of T=20 steps
@@ -8,33 +10,36 @@ class and agent axis sampled INSIDE the kernel (Philox), episodes of T=20 steps
 
 One "step" = one pass of the hot path over the whole per-GPU batch: host subset -> agent axis ->
 shift -> reposition -> Newton polytope -> done/reward for every one of the 65 536 games, finished
-games included (the reference steps them too).  The timed region runs EXACTLY K such steps as
-K//20 episodes of 20 steps (+ one shorter episode of K%20 steps); an episode is ONE launch of the
-fused rollout kernel hk::duo_kernel<20,3,rollout> (two lanes per game; SURVEY.md section 7 stage 5): the state is
-read from HBM once, stays in registers for the 20 steps and is written back once.  Every episode
-restarts from the resident fresh states (the kernel reads them and writes the working state: no
-copy) and is followed by the reduction of the per-step finished-game counts (second tiny kernel).
-Launches are captured once into hipGraphs (10 episodes per graph) and replayed, so python is not
-in the timed loop.
+games included (the reference steps them too).  K steps are K//20 episodes of 20 steps (+ one shorter
+episode of K%20 steps); an episode is ONE launch of the fused rollout kernel: the state is read from
+HBM once, stays in registers for the 20 steps and is written back once.  Every episode restarts
+from the resident fresh states.  The per-step finished-game counts are reduced once per 10 episodes
+(second tiny kernel).  Launches are captured once into hipGraphs and replayed.
 
-N>1: one process per GPU (torch.distributed, backend nccl = RCCL), games sharded by rank
+Timing.  After W untimed warm-up steps and an untimed clock warm-up as long as the measurement, the
+K-step region is REPEATED back to back until >= 0.2 s of GPU time have been timed (`repeats` on the JSON
+line; `steps` stays K).  The whole repeated region is bracketed by barrier + torch.cuda.synchronize()
+on both sides (wall clock, max over ranks -> `value`, `ms_per_step`); HIP events on the launch stream
+split it into 8 segments whose MEDIAN gives `ms_per_step_median` and `roofline.mean_launch_us`.
+
+N>1: `python bench.py --gpus N` starts its own ranks (python -m torch.distributed.run, one process
+per GPU, backend nccl = RCCL) before touching the GPU and relays rank 0's line; launched by
+torch.distributed.run itself it reads RANK / LOCAL_RANK / WORLD_SIZE.  Games are sharded by rank
 (game_offset = rank*batch), no collective in the data path; one all-gather of the final states at
 the end of the timed region (the trainer boundary).  value = steps of ALL ranks / max time.
 
-Also on the JSON line:
-  roofline      the rollout kernel: algorithmic bytes per launch (501 B per env-step, SURVEY.md
-                8(d), x 65 536 games x 20 steps) / mean launch time from HIP events around the
-                timed region.  Because the state never leaves the registers between steps the
-                kernel's real HBM traffic is ~1/20 of the algorithmic figure, so `frac` can exceed
-                1; `traffic` carries the measured bytes when a PMC profile is available.
-  single_step   the same workload as one launch per env step (state through HBM every step: the
-                take_actions-shaped drop-in), with its own algorithmic-bytes roofline figure.
-  cpu_baseline  the scalar C/OpenMP oracle (oracle/hironaka_oracle.c) on this box's host cores,
-                same episodes, bounded sample (rank 0, N=1 only).
+Also on the JSON line (N=1): `roofline` (binding resource of the fused kernel + measured HBM fraction
++ SURVEY 8(d)'s algorithmic figure), `boundary_step` (hk_step, the drop-in boundary, HBM roofline),
+`single_step`, `single_step_dense` (20 live rows: worst case of the domination test), the list / torch
+sibling protocols, the 524 288-game and (50,4) configurations, `config5_mcts_simulate` (BASELINE
+configs[4]) and the CPU baselines (C/OpenMP oracle; torch-CPU array formulation on all cores).
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,13 +47,42 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
-
 DIM, MAX_POINTS, BATCH, MAX_VALUE, EPISODE = 3, 20, 65536, 20, 20
-BLOCK = 10  # episodes captured per hipGraph replay
+BLOCK = 10  # episodes per counter reduction
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# VALU issue ceiling: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles per SIMD at 2.4 GHz
+VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 2
 SEED = 7
+MIN_TIMED_S = 0.2  # GPU time of the headline measurement
+MIN_SECTION_S = 0.04  # ... of every secondary section
+SEGMENTS = 8
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=BATCH, help="games per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-step", action="store_true", help="headline only (skip every secondary section)")
+    ap.add_argument("--no-search", action="store_true", help="skip config5 (MCTS simulate)")
+    return ap.parse_args()
+
+
+def spawn_ranks(args) -> int:
+    """--gpus N > 1 without a launcher: start N ranks as CHILD processes (never exec: this process may not
+    replace itself once anything touched the GPU, and nothing has) and return their exit status.  Rank 0 of the
+    children prints the JSON line on the inherited stdout."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def algorithmic_bytes_per_step(m: int, d: int) -> int:
@@ -56,82 +90,43 @@ def algorithmic_bytes_per_step(m: int, d: int) -> int:
     return 2 * m * d * 4 + 4 * d + 4 + 4 + 1
 
 
-def measured_traffic(key: str):
-    """HBM bytes per launch from the committed rocprofv3 PMC profile (profiles/r*_hbm_traffic.json,
-    written by scripts/summarise_profile.py; FETCH_SIZE x2 on gfx950 + WRITE_SIZE), newest round first.
-    PMC counters cannot be collected from inside the benchmark process, hence the committed file."""
+def profile_constants():
+    """Per-launch PMC figures of the committed rocprofv3 passes (profiles/r*_hbm_traffic.json, written by
+    scripts/summarise_profile.py: HBM bytes = FETCH_SIZE x2 on gfx950 + WRITE_SIZE; SQ_INSTS_VALU), newest round
+    first.  PMC counters cannot be collected from inside the benchmark process, hence the committed file."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
         try:
             with open(path) as f:
                 data = json.load(f)
-            if data.get("batch") == BATCH and key in data:
-                return data[key], os.path.relpath(path, ROOT)
+            if data.get("batch") == BATCH:
+                return data, os.path.relpath(path, ROOT)
         except (OSError, ValueError):
             continue
-    return None, None
-
-
-def cpu_array_baseline(games: int = 8192):
-    """The reference's own CPU formulation of the step -- broadcast [B,m,m,d] difference tensors and masks, as
-    in _jax_ops.py / _torch_ops.py -- restated in numpy (oracle/np_oracle.py), one 20-step episode of a bounded
-    sample.  (SURVEY 6 measured the reference's torch ops themselves at 0.09-0.11 M env-steps/s on 8 cores.)"""
-    from oracle import np_oracle as NO
-    fresh = NO.generate_points(games, MAX_POINTS, DIM, MAX_VALUE, 42)
-    t0 = time.perf_counter()
-    NO.rollout(fresh, EPISODE, SEED)
-    dt = time.perf_counter() - t0
-    return {"value": games * EPISODE / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"1 episode of {games} games x {EPISODE} steps ({dt:.1f} s) with oracle/np_oracle.py (numpy, the "
-                      f"reference's broadcast-tensor formulation)"}
-
-
-def capture(fn):
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        fn()
-    return g
-
-
-def cpu_baseline(seconds: float = 12.0):
-    """C/OpenMP oracle on the host cores: the same episodes (64k games x 20 steps), repeated
-    until `seconds` of CPU work were timed."""
-    from oracle import c_oracle as CO
-    from hironaka_amd import _abi as A
-    threads = CO.set_threads(0)
-    fresh = CO.generate_points(BATCH, MAX_POINTS, DIM, MAX_VALUE, 42)
-    stages = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON
-    CO.rollout(fresh[:4096], EPISODE, SEED, record=False, stages=stages)  # warm-up
-    done, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        CO.rollout(fresh, EPISODE, SEED, record=False, stages=stages)
-        done += BATCH * EPISODE
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{done // (BATCH * EPISODE)} episodes of {BATCH} games x {EPISODE} steps "
-                      f"({dt:.1f} s) with oracle/hironaka_oracle.c (scalar C + OpenMP, {threads} threads "
-                      f"on {os.cpu_count()} logical cores)"}
+    return {}, None
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200000)
-    ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--batch", type=int, default=BATCH, help="games per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-single-step", action="store_true")
-    args = ap.parse_args()
-
+    args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+
+    import torch
+    import torch.distributed as dist
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     # HK_BENCH_BACKEND=gloo rehearses the multi-rank flow on a box with fewer GPUs than ranks (ranks then
     # share devices and the final gather is staged through host memory); the real path is nccl = RCCL.
     backend = os.environ.get("HK_BENCH_BACKEND", "nccl")
-    device_index = local_rank % max(1, torch.cuda.device_count())
+    n_dev = max(1, torch.cuda.device_count())
+    if world > n_dev and backend == "nccl":
+        raise SystemExit(f"--gpus {world} needs {world} devices, this box has {n_dev} "
+                         f"(HK_BENCH_BACKEND=gloo rehearses the flow with ranks sharing a device)")
+    device_index = local_rank % n_dev
     torch.cuda.set_device(device_index)
     distributed = world > 1
     if distributed:
@@ -142,6 +137,7 @@ def main():
             dist.init_process_group(backend)
 
     from hironaka_amd import _abi as A
+    from hironaka_amd import distributed as hkdist
     from hironaka_amd import ops
 
     b, m, d = args.batch, MAX_POINTS, DIM
@@ -151,7 +147,28 @@ def main():
     state = torch.empty_like(fresh)
     done_count = torch.zeros(EPISODE + 1, dtype=torch.int64, device="cuda")
     step_counts = torch.zeros((EPISODE, 2), dtype=torch.int64, device="cuda")
-    from hironaka_amd import distributed as hkdist
+    side = torch.cuda.Stream()
+
+    def capture(fn):
+        with torch.cuda.stream(side):
+            fn()  # eager first: allocations and lazy initialisation happen outside the capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+        torch.cuda.synchronize()
+        return g
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(values):
+        t = torch.tensor(values, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        if distributed:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
 
     def gather_final_states():
         """the trainer boundary: every rank ends up with all B*world final states"""
@@ -161,218 +178,229 @@ def main():
             return hkdist.all_gather_games(state)
         return hkdist.all_gather_games(state.cpu())
 
-    def max_over_ranks(x: float) -> float:
-        if not distributed:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+    def timed_replays(replay, min_seconds):
+        """`replay()` enqueues one unit of work (graph replays) on the current stream.  Estimate its duration,
+        run an untimed clock warm-up as long as the measurement, then time SEGMENTS segments of n units each
+        with HIP events on the launch stream.  Returns (median, mean) seconds per unit and the unit count."""
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(SEGMENTS + 1)]
+        replay()
+        torch.cuda.synchronize()
+        e[0].record()
+        for _ in range(3):
+            replay()
+        e[1].record()
+        torch.cuda.synchronize()
+        est = max(e[0].elapsed_time(e[1]) / 3e3, 1e-7)
+        n = max(1, math.ceil(min_seconds / SEGMENTS / est))
+        for _ in range(SEGMENTS * n):  # clock warm-up
+            replay()
+        torch.cuda.synchronize()
+        e[0].record()
+        for s in range(SEGMENTS):
+            for _ in range(n):
+                replay()
+            e[s + 1].record()
+        torch.cuda.synchronize()
+        seg = sorted(e[s].elapsed_time(e[s + 1]) / 1e3 / n for s in range(SEGMENTS))
+        return 0.5 * (seg[SEGMENTS // 2 - 1] + seg[SEGMENTS // 2]), sum(seg) / SEGMENTS, SEGMENTS * n
+
     K, W = args.steps, args.warmup
     n_full, rem = divmod(K, EPISODE)
     kw = dict(game_offset=game_offset, stages=stages, host_policy=A.HK_HOST_RANDOM,
               agent_policy=A.HK_AGENT_RANDOM)
-
     count_ws = ops.rollout_workspace(b, EPISODE, (m, d))
 
-    def episode(n_steps):
-        # the episode restarts from the resident fresh states: the kernel reads `fresh`, writes `state`
-        ops.rollout(state, n_steps, SEED, done_count=done_count[: n_steps + 1], initial=fresh, **kw)
-
-    def episodes_deferred(n_episodes):
-        # full episodes back to back; the per-workgroup finished-game counts accumulate in `count_ws` and are
-        # summed into done_count ONCE (the reference sums its per-loop histograms the same way,
-        # jax_trainer.py:513,533-534)
+    def episodes_deferred(n_episodes, n_steps=EPISODE):
+        # episodes back to back, each restarting from the resident fresh states (the kernel reads `fresh`, writes
+        # `state`: no copy); the per-workgroup finished-game counts accumulate in `count_ws`
         for _ in range(n_episodes):
-            ops.rollout(state, EPISODE, SEED, initial=fresh, defer_counts=True, workspace=count_ws, **kw)
+            ops.rollout(state, n_steps, SEED, initial=fresh, defer_counts=True, workspace=count_ws, **kw)
+
+    def reduce_counts():
+        # ... and are summed into done_count once per BLOCK episodes (the reference sums its per-loop histograms
+        # the same way, jax_trainer.py:513,533-534)
         ops.reduce_counts(count_ws, done_count, b, EPISODE, (m, d))
 
-    def episode_stepwise(n_steps):
-        for t in range(n_steps):
-            ops.rollout(state, 1, SEED, step_offset=t, done_count=step_counts[t],
-                        initial=fresh if t == 0 else None, **kw)
+    g_block = capture(lambda: episodes_deferred(BLOCK)) if n_full >= BLOCK else None
+    g_episode = capture(lambda: episodes_deferred(1))
+    g_rem = capture(lambda: episodes_deferred(1, rem)) if rem else None
+    g_reduce = capture(reduce_counts)
+    launches_per_region = n_full + (1 if rem else 0)
+    reduce_every = max(1, BLOCK // max(1, launches_per_region))  # regions between two counter reductions
 
-    side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        episode(EPISODE)  # allocates the rollout workspace outside of any capture
-        episode_stepwise(1)
-        torch.cuda.synchronize()
-        g_episode = capture(lambda: episode(EPISODE))
-        episodes_deferred(1)
-        torch.cuda.synchronize()
-        g_block = capture(lambda: episodes_deferred(BLOCK))  # BLOCK episodes + one counter reduce per replay
-        g_rem = capture(lambda: episode(rem)) if rem else None
-        g_stepwise = None if args.no_single_step else capture(lambda: episode_stepwise(EPISODE))
-    torch.cuda.synchronize()
+    def region():
+        """exactly K env steps"""
+        for _ in range(n_full // BLOCK):
+            g_block.replay()
+        for _ in range(n_full % BLOCK):
+            g_episode.replay()
+        if g_rem is not None:
+            g_rem.replay()
 
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def regions(count, start=0):
+        for r in range(start, start + count):
+            region()
+            if (r + 1) % reduce_every == 0:
+                g_reduce.replay()
 
-    # ---- warm-up (untimed) -------------------------------------------------------------------
+    # ---- warm-up (untimed): W steps, then a clock warm-up as long as the measurement ----------------------------
     for _ in range(max(1, W // EPISODE)):
         g_episode.replay()
+    g_reduce.replay()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(SEGMENTS + 1)]
+    ev[0].record()
+    regions(3 * reduce_every)
+    ev[1].record()
+    torch.cuda.synchronize()
+    est = max(ev[0].elapsed_time(ev[1]) / 1e3 / (3 * reduce_every), 1e-7)
+    per_seg = max(1, math.ceil(MIN_TIMED_S / SEGMENTS / est))
+    per_seg = int(max_over_ranks([math.ceil(per_seg / reduce_every) * reduce_every])[0])  # the same on every rank
+    repeats = SEGMENTS * per_seg
+    regions(repeats)
     gather_final_states()
     barrier()
 
-    # ---- exactly K timed steps ---------------------------------------------------------------
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # ---- the timed region: `repeats` x exactly K steps ----------------------------------------------------------
     done_count.zero_()
     barrier()
     t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(n_full // BLOCK):
-        g_block.replay()
-    for _ in range(n_full % BLOCK):
-        g_episode.replay()
-    if g_rem is not None:
-        g_rem.replay()
-    ev1.record()
+    ev[0].record()
+    for s in range(SEGMENTS):
+        regions(per_seg, s * per_seg)
+        ev[s + 1].record()
     final_states = gather_final_states()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
-    region_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream, around the K steps
+    elapsed = max_over_ranks([time.perf_counter() - t0])[0]
+    seg_s = max_over_ranks([ev[s].elapsed_time(ev[s + 1]) / 1e3 for s in range(SEGMENTS)])
     assert final_states.shape[0] == world * b
-    finished = int(done_count[EPISODE].item()) // max(1, n_full) if n_full else 0
+    seg_sorted = sorted(seg_s)
+    median_region_s = 0.5 * (seg_sorted[SEGMENTS // 2 - 1] + seg_sorted[SEGMENTS // 2]) / per_seg
+    timed_episodes = repeats * n_full
+    finished = int(done_count[EPISODE].item()) // timed_episodes if timed_episodes else 0
 
-    # ---- the one-launch-per-step variant, timed separately (rank 0's shard) --------------------
-    single = None
-    if g_stepwise is not None:
-        n_ep = max(1, min(n_full, 50))
-        g_stepwise.replay()
-        barrier()
-        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s0.record()
-        for _ in range(n_ep):
-            g_stepwise.replay()
-        s1.record()
-        torch.cuda.synchronize()
-        step_s = s0.elapsed_time(s1) / 1e3 / (n_ep * EPISODE)
+    extras = world == 1 and b == BATCH and not args.no_single_step
+    bytes_step = algorithmic_bytes_per_step(m, d)
+    prof, prof_src = profile_constants()
+
+    def hbm_roofline(seconds, nbytes, traffic=None, kernel=None):
+        gbps = nbytes / seconds / 1e9
+        r = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
+             "traffic": traffic, "algorithmic_bytes_per_launch": int(nbytes), "mean_launch_us": seconds * 1e6}
+        if kernel:
+            r["kernel"] = kernel
+        if traffic:
+            r["traffic_source"] = prof_src
+        return r
+
+    # ---- the one-launch-per-step variants (rank 0's shard, N=1 only) ----------------------------------------------
+    single = api = dense = legal = large = config3 = config5 = None
+    if extras:
+        def episode_stepwise():
+            for t in range(EPISODE):
+                ops.rollout(state, 1, SEED, step_offset=t, done_count=step_counts[t],
+                            initial=fresh if t == 0 else None, **kw)
+
+        g_stepwise = capture(episode_stepwise)
+        med, mean, n = timed_replays(g_stepwise.replay, MIN_SECTION_S)
+        step_s = med / EPISODE
         single = {"value": b / step_s, "unit": "env-steps/s per GPU", "us_per_step": step_s * 1e6,
-                  "steps": n_ep * EPISODE,
-                  "algorithmic_GBps": b * algorithmic_bytes_per_step(m, d) / step_s / 1e9,
-                  "frac_of_hbm_peak": b * algorithmic_bytes_per_step(m, d) / step_s / 1e9 / HBM_PEAK_GBS,
-                  "note": "one launch of hk::duo_kernel<20,3,rollout> (T=1) + counter reduce per env step; "
-                          "state read from and written to HBM every step"}
+                  "steps": n * EPISODE,
+                  "roofline": hbm_roofline(step_s, b * bytes_step, prof.get("single_step_bytes_per_launch")),
+                  "note": "one launch of the rollout kernel with T=1 (policies in-kernel) + counter reduce per env "
+                          "step; state read from and written to HBM every step"}
 
-    def time_boundary_steps(start, n_ep):
-        """seconds per hk_step launch, over episodes of EPISODE steps from `start` with pre-drawn actions"""
+    def boundary_graph(start, flags=0, coords_as_class=False):
+        """one episode of hk_step launches (pre-drawn actions, ping-pong state buffers) as a hipGraph"""
         nb = start.shape[0]
-        cls = torch.randint(0, 2 ** d - d - 1, (EPISODE, nb), dtype=torch.int32, device="cuda")
-        masks = ops.decode_host_class(cls.reshape(-1), d, torch.float32).reshape(EPISODE, nb, d).contiguous()
-        axes = torch.randint(0, d, (EPISODE, nb), dtype=torch.int32, device="cuda")
+        dd = start.shape[2]
+        cls = torch.randint(0, 2 ** dd - dd - 1, (EPISODE, nb), dtype=torch.int32, device="cuda")
+        masks = cls if coords_as_class else \
+            ops.decode_host_class(cls.reshape(-1), dd, torch.float32).reshape(EPISODE, nb, dd).contiguous()
+        axes = torch.randint(0, dd, (EPISODE, nb), dtype=torch.int32, device="cuda")
         bufs = [torch.empty_like(start), torch.empty_like(start)]
 
         def episode_api():
             src = start
             for t in range(EPISODE):
-                ops.step(src, masks[t], axes[t], stages=stages, out=bufs[t & 1], want=("done", "reward"))
+                ops.step(src, masks[t], axes[t], stages=stages, flags=flags, out=bufs[t & 1], want=("done", "reward"))
                 src = bufs[t & 1]
 
-        with torch.cuda.stream(side):
-            episode_api()
-            torch.cuda.synchronize()
-            g_api = capture(episode_api)
-        torch.cuda.synchronize()
-        g_api.replay()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n_ep):
-            g_api.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / 1e3 / (n_ep * EPISODE)
+        return capture(episode_api)
 
-    # ---- the drop-in boundary itself: hk_step with the trainer's arrays (state in, [B,d] subset mask and
-    # [B] axis in, state + done + reward out) -- exactly SURVEY 8(d)'s 501 algorithmic bytes per env step ----
-    api = None
-    if g_stepwise is not None:
-        api_s = time_boundary_steps(fresh, max(1, min(n_full, 50)))
+    if extras:
+        # ---- the drop-in boundary itself: hk_step with the trainer's arrays (state in, [B,d] subset mask and
+        # [B] axis in, state + done + reward out) -- exactly SURVEY 8(d)'s 501 algorithmic bytes per env step ----
+        g_api = boundary_graph(fresh)
+        med, mean, n = timed_replays(g_api.replay, MIN_SECTION_S)
+        api_s = med / EPISODE
         # what a plain device-to-device copy reaches on this box (read + write bytes per second)
         big = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
         dst = torch.empty_like(big)
-        dst.copy_(big)
-        torch.cuda.synchronize()
-        s0.record()
-        for _ in range(10):
-            dst.copy_(big)
-        s1.record()
-        torch.cuda.synchronize()
-        copy_gbps = 10 * 2 * big.numel() * 4 / (s0.elapsed_time(s1) / 1e3) / 1e9
+        cmed, _, _ = timed_replays(lambda: dst.copy_(big), MIN_SECTION_S)
+        copy_gbps = 2 * big.numel() * 4 / cmed / 1e9
         del big, dst
         # ... and what a copy of exactly one state batch (15.7 MB in, 15.7 MB out: the traffic of one hk_step)
         # takes as a kernel of its own, replayed from a hipGraph like the steps above
         same = torch.empty_like(fresh)
-        with torch.cuda.stream(side):
-            same.copy_(fresh)
-            torch.cuda.synchronize()
-            g_copy = capture(lambda: [same.copy_(fresh) for _ in range(20)])
-        torch.cuda.synchronize()
-        g_copy.replay()
-        torch.cuda.synchronize()
-        s0.record()
-        for _ in range(10):
-            g_copy.replay()
-        s1.record()
-        torch.cuda.synchronize()
-        same_us = s0.elapsed_time(s1) * 1e3 / 200
+        g_copy = capture(lambda: [same.copy_(fresh) for _ in range(20)])
+        smed, _, _ = timed_replays(g_copy.replay, MIN_SECTION_S)
         del same
-        gbps = b * algorithmic_bytes_per_step(m, d) / api_s / 1e9
-        api = {"value": b / api_s, "unit": "env-steps/s per GPU", "us_per_step": api_s * 1e6,
-               "steps": max(1, min(n_full, 50)) * EPISODE, "algorithmic_GBps": gbps,
-               "frac_of_hbm_peak": gbps / HBM_PEAK_GBS, "device_copy_GBps": copy_gbps, "frac_of_device_copy": gbps / copy_gbps,
-               "state_copy_us": same_us,
-               "note": "one hk_step launch per env step (hk::duo_kernel<20,3,step,jax>): f32 state + f32 [B,d] mask "
-                       "+ i32 axis read from HBM, state + done + reward written back; device_copy_GBps = a 1 GiB "
-                       "device-to-device copy, state_copy_us = a copy kernel over one state batch (the same bytes as "
-                       "one hk_step without the actions and outcomes)"}
+        api = {"value": b / api_s, "unit": "env-steps/s per GPU", "us_per_step": api_s * 1e6, "steps": n * EPISODE,
+               "roofline": hbm_roofline(api_s, b * bytes_step, prof.get("boundary_step_bytes_per_launch"),
+                                        f"hk_step at {b} games (JAX-trainer configuration)"),
+               "device_copy_GBps": copy_gbps, "frac_of_device_copy": b * bytes_step / api_s / 1e9 / copy_gbps,
+               "state_copy_us": smed / 20 * 1e6,
+               "note": "one hk_step launch per env step over an episode from generate_pts states: f32 state + f32 "
+                       "[B,d] mask + i32 axis read from HBM, state + done + reward written back; device_copy_GBps = "
+                       "a 1 GiB device-to-device copy, state_copy_us = a copy kernel over one state batch (the same "
+                       "bytes as one hk_step without the actions and outcomes)"}
 
-    # ---- SURVEY 8(d), config 2's second protocol: the agent draws its axis among the host's coordinates
-    # only, under the torch and the list sibling's semantics (illegal / finished games not shifted; list:
-    # survivors sorted + compacted after every step) -- fused 20-step rollouts and single hk_step launches ----
-    legal = None
-    if world == 1 and b == BATCH and not args.no_single_step:
+        # ---- SURVEY 8(d): "single-step from fresh states (all 20 points live -- worst case for the domination
+        # test)": hk_step from randint states BEFORE any Newton pass, 20 launches per graph, all from the same input
+        fresh_dense = ops.generate_points(b, m, d, MAX_VALUE, seed=43, newton=False, reposition=False)
+        live = float(ops.get_num_points(fresh_dense).float().mean().item())
+        cls_d = torch.randint(0, 2 ** d - d - 1, (b,), dtype=torch.int32, device="cuda")
+        mask_d = ops.decode_host_class(cls_d, d, torch.float32)
+        axis_d = torch.randint(0, d, (b,), dtype=torch.int32, device="cuda")
+        out_d = torch.empty_like(fresh_dense)
+        g_dense = capture(lambda: [ops.step(fresh_dense, mask_d, axis_d, stages=stages, out=out_d,
+                                            want=("done", "reward")) for _ in range(EPISODE)])
+        med, _, n = timed_replays(g_dense.replay, MIN_SECTION_S)
+        dense_s = med / EPISODE
+        dense = {"value": b / dense_s, "unit": "env-steps/s per GPU", "us_per_step": dense_s * 1e6,
+                 "steps": n * EPISODE, "mean_live_points": live,
+                 "roofline": hbm_roofline(dense_s, b * bytes_step),
+                 "pair_tests_per_game": m * (m - 1) // 2,
+                 "note": "hk_step from generate_points(newton=False) states: every game holds 20 live rows, the "
+                         "domination test runs all 190 pairs (rollout states hold ~5)"}
+        del fresh_dense, out_d
+
+        # ---- SURVEY 8(d), config 2's second protocol: the agent draws its axis among the host's coordinates
+        # only, under the torch and the list sibling's semantics (illegal / finished games not shifted; list:
+        # survivors sorted + compacted after every step) -- fused 20-step rollouts and hk_step episodes ----
         legal = {"agent": "uniform over the host's subset (HK_AGENT_RANDOM_LEGAL)"}
-        cls_l = torch.randint(0, 2 ** d - d - 1, (b,), dtype=torch.int32, device="cuda")
-        axis_l = torch.zeros(b, dtype=torch.int32, device="cuda")  # coordinate 0 is in 3 of the 4 subsets
-        out_l = torch.empty_like(fresh)
         for sem in ("torch", "list"):
             fl = ops.make_flags(sem, noop_if_invalid=True, ignore_ended=True)
 
             def roll_sem():
-                ops.rollout(state, EPISODE, SEED, done_count=done_count, initial=fresh, stages=stages, flags=fl,
-                            host_policy=A.HK_HOST_RANDOM, agent_policy=A.HK_AGENT_RANDOM_LEGAL)
+                for _ in range(BLOCK):
+                    ops.rollout(state, EPISODE, SEED, initial=fresh, stages=stages, flags=fl, defer_counts=True,
+                                workspace=count_ws, host_policy=A.HK_HOST_RANDOM, agent_policy=A.HK_AGENT_RANDOM_LEGAL)
+                ops.reduce_counts(count_ws, done_count, b, EPISODE, (m, d))
 
-            def step_sem():
-                ops.step(fresh, cls_l, axis_l, stages=stages, flags=fl, out=out_l, want=("done", "reward"))
-
-            ts = []
-            for fn in (roll_sem, step_sem):
-                with torch.cuda.stream(side):
-                    fn()
-                    torch.cuda.synchronize()
-                    gl = capture(lambda: [fn() for _ in range(10)])
-                torch.cuda.synchronize()
-                gl.replay()
-                torch.cuda.synchronize()
-                l0, l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                l0.record()
-                for _ in range(10):
-                    gl.replay()
-                l1.record()
-                torch.cuda.synchronize()
-                ts.append(l0.elapsed_time(l1) / 1e3 / 100)
-            legal[sem] = {"fused_rollout_us_per_episode": ts[0] * 1e6, "fused_env_steps_per_s": b * EPISODE / ts[0],
-                          "hk_step_us": ts[1] * 1e6, "hk_step_env_steps_per_s": b / ts[1]}
+            rmed, _, _ = timed_replays(capture(roll_sem).replay, MIN_SECTION_S)
+            smed, _, _ = timed_replays(boundary_graph(fresh, flags=fl, coords_as_class=True).replay, MIN_SECTION_S)
+            legal[sem] = {"fused_rollout_us_per_episode": rmed / BLOCK * 1e6,
+                          "fused_env_steps_per_s": b * EPISODE * BLOCK / rmed,
+                          "hk_step_us": smed / EPISODE * 1e6, "hk_step_env_steps_per_s": b * EPISODE / smed,
+                          "hk_step_frac_of_hbm_peak": b * bytes_step * EPISODE / smed / 1e9 / HBM_PEAK_GBS}
         done_count.zero_()
 
-    # ---- same kernels at the batch that saturates one GPU (BASELINE configs[3]'s 524 288 games on ONE
-    # device): one lane per game means 65 536 games are only 1024 instruction streams for 1024 SIMDs ----
-    large = None
-    if world == 1 and b == BATCH and not args.no_single_step:
+        # ---- same kernels at the batch that saturates one GPU (BASELINE configs[3]'s 524 288 games on ONE
+        # device): one lane per game means 65 536 games are only 1024 instruction streams for 1024 SIMDs ----
         bl = 8 * BATCH
         fresh_l = ops.generate_points(bl, m, d, MAX_VALUE, seed=42)
         state_l = torch.empty_like(fresh_l)
@@ -388,139 +416,148 @@ def main():
                 ops.rollout(state_l, 1, SEED, step_offset=t, done_count=sc_l[t],
                             initial=fresh_l if t == 0 else None, **kw_l)
 
-        with torch.cuda.stream(side):
-            ep_fused()
-            ep_steps()
-            torch.cuda.synchronize()
-            gf, gs = capture(ep_fused), capture(ep_steps)
-        torch.cuda.synchronize()
-        times = []
-        for gr in (gf, gs):
-            gr.replay()
-            torch.cuda.synchronize()
-            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a0.record()
-            for _ in range(20):
-                gr.replay()
-            a1.record()
-            torch.cuda.synchronize()
-            times.append(a0.elapsed_time(a1) / 1e3 / (20 * EPISODE))
-        bs = algorithmic_bytes_per_step(m, d)
-        api_l = time_boundary_steps(fresh_l, 20)
-        large = {"batch": bl, "boundary_step_us": api_l * 1e6,
-                 "boundary_step_frac_of_hbm_peak": bl * bs / api_l / 1e9 / HBM_PEAK_GBS, "fused_env_steps_per_s": bl / times[0], "single_step_env_steps_per_s": bl / times[1],
-                 "single_step_us": times[1] * 1e6, "single_step_algorithmic_GBps": bl * bs / times[1] / 1e9,
-                 "single_step_frac_of_hbm_peak": bl * bs / times[1] / 1e9 / HBM_PEAK_GBS,
+        fmed, _, _ = timed_replays(capture(ep_fused).replay, MIN_SECTION_S)
+        smed, _, _ = timed_replays(capture(ep_steps).replay, MIN_SECTION_S)
+        amed, _, _ = timed_replays(boundary_graph(fresh_l).replay, MIN_SECTION_S)
+        large = {"batch": bl, "boundary_step_us": amed / EPISODE * 1e6,
+                 "boundary_step_frac_of_hbm_peak": bl * bytes_step * EPISODE / amed / 1e9 / HBM_PEAK_GBS,
+                 "fused_env_steps_per_s": bl * EPISODE / fmed, "fused_us_per_episode": fmed * 1e6,
+                 "single_step_env_steps_per_s": bl * EPISODE / smed, "single_step_us": smed / EPISODE * 1e6,
+                 "single_step_frac_of_hbm_peak": bl * bytes_step * EPISODE / smed / 1e9 / HBM_PEAK_GBS,
                  "note": "not the headline config: shows where the kernels saturate one MI355X"}
         del fresh_l, state_l
 
-    # ---- BASELINE configs[2]: dim 4, 50 points, 262 144 games on one GPU (the team kernel: four lanes per
-    # game); a parity-test configuration, measured here so that its numbers come from the same run --------
-    config3 = None
-    if world == 1 and b == BATCH and not args.no_single_step:
+        # ---- BASELINE configs[2]: dim 4, 50 points, 262 144 games on one GPU; a parity-test configuration,
+        # measured here so that its numbers come from the same run --------
         m3, d3, b3 = 50, 4, 262144
         fresh3 = ops.generate_points(b3, m3, d3, MAX_VALUE, seed=42)
+        state3 = torch.empty_like(fresh3)
+        dc3 = torch.zeros(EPISODE + 1, dtype=torch.int64, device="cuda")
         cls3 = torch.randint(0, 2 ** d3 - d3 - 1, (b3,), dtype=torch.int32, device="cuda")
         mask3 = ops.decode_host_class(cls3, d3, torch.float32)
         axis3 = torch.randint(0, d3, (b3,), dtype=torch.int32, device="cuda")
         out3 = torch.empty_like(fresh3)
-        state3 = torch.empty_like(fresh3)
-        dc3 = torch.zeros(EPISODE + 1, dtype=torch.int64, device="cuda")
-
-        def step3():
-            ops.step(fresh3, mask3, axis3, stages=stages, out=out3, want=("done", "reward"))
+        dense3 = ops.generate_points(b3, m3, d3, MAX_VALUE, seed=43, newton=False, reposition=False)
 
         def roll3():
             ops.rollout(state3, EPISODE, SEED, done_count=dc3, initial=fresh3, stages=stages,
                         host_policy=A.HK_HOST_RANDOM, agent_policy=A.HK_AGENT_RANDOM)
 
-        times3 = []
-        for fn in (step3, roll3):
-            with torch.cuda.stream(side):
-                fn()
-                torch.cuda.synchronize()
-                g3 = capture(lambda: [fn() for _ in range(5)])
-            torch.cuda.synchronize()
-            g3.replay()
-            torch.cuda.synchronize()
-            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            c0.record()
-            for _ in range(4):
-                g3.replay()
-            c1.record()
-            torch.cuda.synchronize()
-            times3.append(c0.elapsed_time(c1) / 1e3 / 20)
         bs3 = algorithmic_bytes_per_step(m3, d3)
-        config3 = {"workload": f"dim={d3}, max_points={m3}, batch={b3} (BASELINE configs[2]), hk::team_kernel<4>",
-                   "hk_step_us": times3[0] * 1e6, "hk_step_env_steps_per_s": b3 / times3[0],
-                   "hk_step_algorithmic_GBps": b3 * bs3 / times3[0] / 1e9,
-                   "hk_step_frac_of_hbm_peak": b3 * bs3 / times3[0] / 1e9 / HBM_PEAK_GBS,
-                   "fused_rollout_us_per_episode": times3[1] * 1e6,
-                   "fused_env_steps_per_s": b3 * EPISODE / times3[1],
+        s3, _, _ = timed_replays(capture(lambda: [ops.step(fresh3, mask3, axis3, stages=stages, out=out3,
+                                                           want=("done", "reward")) for _ in range(5)]).replay,
+                                 MIN_SECTION_S)
+        s3d, _, _ = timed_replays(capture(lambda: [ops.step(dense3, mask3, axis3, stages=stages, out=out3,
+                                                            want=("done", "reward")) for _ in range(2)]).replay,
+                                  MIN_SECTION_S)
+        r3, _, _ = timed_replays(capture(roll3).replay, MIN_SECTION_S)
+        c3, _, _ = timed_replays(capture(lambda: out3.copy_(fresh3)).replay, MIN_SECTION_S)
+        config3 = {"workload": f"dim={d3}, max_points={m3}, batch={b3} (BASELINE configs[2])",
+                   "hk_step_us": s3 / 5 * 1e6, "hk_step_env_steps_per_s": b3 * 5 / s3,
+                   "roofline": hbm_roofline(s3 / 5, b3 * bs3, kernel="hk_step at (50,4) x 262144 from generate_pts states"),
+                   "hk_step_dense_us": s3d / 2 * 1e6,
+                   "hk_step_dense_note": "50 live rows per game: 1225 pair tests per game, VALU-bound",
+                   "state_copy_us": c3 * 1e6,
+                   "fused_rollout_us_per_episode": r3 * 1e6, "fused_env_steps_per_s": b3 * EPISODE / r3,
                    "algorithmic_bytes_per_env_step": bs3}
-        del fresh3, out3, state3
+        del fresh3, out3, state3, dense3
+
+    # ---- BASELINE configs[4]: JAXTrainer.simulate-shaped MCTS self-play (8192 games, 32 simulations per move,
+    # 20 moves) through hironaka_amd.trainer_api.HipTrainer; networks are stand-ins (out of scope) ------------
+    if extras and not args.no_search:
+        from hironaka_amd.trainer_api import HipTrainer, standin_mlp
+        cfg = {"eval_batch_size": 8192, "max_num_points": m, "dimension": d, "max_length_game": EPISODE,
+               "max_value": MAX_VALUE, "scale_observation": True, "reposition": True, "gumbel_scale": 0.3,
+               "num_evaluations": 32, "num_evaluations_as_opponent": 8, "max_num_considered_actions": 10,
+               "discount": 0.99}
+        host_net, host_params = standin_mlp(m * d, 2 ** d - d - 1, 3)
+        agent_net, agent_params = standin_mlp(m * d + d, d, 4)
+        trainer = HipTrainer(1, cfg, host_net=host_net, agent_net=agent_net, host_params=host_params,
+                             agent_params=agent_params, use_graph=True)
+        trainer.simulate(0, "host")  # captures one hipGraph per search shape
+        torch.cuda.synchronize()
+        reps, t5 = 3, time.perf_counter()
+        for r in range(reps):
+            obs5, _, _ = trainer.simulate(r + 1, "host")
+        torch.cuda.synchronize()
+        dt5 = (time.perf_counter() - t5) / reps
+        env5 = cfg["eval_batch_size"] * cfg["num_evaluations"] * EPISODE
+        config5 = {"workload": "HipTrainer.simulate(key, 'host'): dim=3, max_points=20, batch=8192, 32 simulations "
+                               "per move, 20 moves (BASELINE configs[4]); opponent = the agent network's argmax",
+                   "policy_network": "stand-in: fixed random MLPs 60-256-5 / 63-256-4 behind the HIP feature "
+                                     "transform (the reference's flax networks are out of scope)",
+                   "launches": "one hipGraph per search (32 simulations), replayed per move",
+                   "seconds_per_simulate": dt5, "env_steps_in_search_per_s": env5 / dt5,
+                   "searches_per_s": cfg["eval_batch_size"] * EPISODE / dt5, "samples": list(obs5.shape),
+                   "hip_kernel_share_of_gpu_time": prof.get("search_hip_kernel_share"),
+                   "hip_kernel_share_source": prof_src if prof.get("search_hip_kernel_share") is not None else None}
+        del trainer
 
     if rank == 0:
-        bytes_step = algorithmic_bytes_per_step(m, d)
-        launches = n_full + (1 if rem else 0)
-        launch_s = (region_ms / 1e3) / max(1, launches)
-        steps_per_launch = K / max(1, launches)
-        achieved = b * bytes_step * steps_per_launch / launch_s / 1e9
-        traffic, traffic_src = (None, None)
-        if b == BATCH and rem == 0:
-            traffic, traffic_src = measured_traffic("rollout_T20_bytes_per_launch")
-        if single is not None and b == BATCH:
-            single["traffic"], _ = measured_traffic("single_step_bytes_per_launch")
-        if api is not None and b == BATCH:
-            api["traffic"], _ = measured_traffic("boundary_step_bytes_per_launch")
+        launch_s = median_region_s / max(1, launches_per_region)  # per rollout launch (+ its share of the reduce)
+        steps_per_launch = K / max(1, launches_per_region)
+        alg_bytes = b * bytes_step * steps_per_launch
+        full = b == BATCH and rem == 0
+        traffic = prof.get("rollout_T20_bytes_per_launch") if full else None
+        valu = prof.get("rollout_T20_valu_insts_per_launch") if full else None
+        roofline = {
+            # the fused kernel keeps the state in registers for 20 steps: what binds it is instruction issue
+            "bound": "valu_issue",
+            "kernel": f"fused rollout kernel, {b} games x {EPISODE} steps per launch, two lanes per game",
+            "achieved": (valu / launch_s) if valu else None,
+            "peak": VALU_PEAK_WAVE_INSTS,
+            "unit": "wave64 VALU instructions/s",
+            "frac": (valu / launch_s / VALU_PEAK_WAVE_INSTS) if valu else None,
+            "valu_insts_per_launch": valu,
+            "traffic": traffic,
+            "traffic_source": prof_src,
+            "hbm_frac_measured": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "algorithmic_bytes_per_launch": int(alg_bytes),
+            "algorithmic_GBps": alg_bytes / launch_s / 1e9,
+            "algorithmic_frac": alg_bytes / launch_s / 1e9 / HBM_PEAK_GBS,
+            "mean_launch_us": launch_s * 1e6,
+            "note": "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction; valu_insts_per_launch "
+                    "(SQ_INSTS_VALU) and traffic (2 x FETCH_SIZE + WRITE_SIZE) come from the committed rocprofv3 "
+                    "PMC passes; algorithmic_* = SURVEY 8(d)'s 501 B/env-step x games x steps (may exceed 1: the "
+                    "state stays in registers between steps, real traffic is ~2 x 240 B per game per launch); the "
+                    "HBM-bound kernel of this path is hk_step: see boundary_step.roofline",
+        }
         out = {
             "metric": "env-steps/sec at dim=3, max_pts=20, batch=65536; 1/2/4/8 GPUs",
-            "value": world * b * K / elapsed,
+            "value": world * b * K * repeats / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
             "steps": K,
             "warmup": W,
-            "ms_per_step": elapsed / K * 1e3,
+            "ms_per_step": elapsed / (K * repeats) * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "repeats": repeats,
+            "timed_steps": K * repeats,
+            "timed_seconds": elapsed,
+            "ms_per_step_median": median_region_s / K * 1e3,
+            "value_from_median": world * b * K / median_region_s,
             "config": {
                 "workload": f"dim={d}, max_points={m}, batch={b} games per GPU (BASELINE configs[1]), random "
                             f"host+agent policies sampled in-kernel, reposition=True, rescale=False, episodes of "
                             f"{EPISODE} steps from generate_pts states (max_value={MAX_VALUE}); fused rollout: "
                             f"{EPISODE} env steps per launch",
-                "parallelism": f"{world} x independent game shards, all-gather of final states",
-                "launch": f"hipGraph replay ({BLOCK} episodes per graph): one rollout kernel per episode, one "
-                          f"counter reduce per graph",
+                "parallelism": f"{world} x independent game shards, one all-gather of final states inside the "
+                               f"timed region",
+                "launch": f"hipGraph replays: one rollout kernel per episode, one counter reduce per {BLOCK} "
+                          f"episodes; the K-step region repeated {repeats}x inside one barrier+synchronize bracket",
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": f"hk::duo_kernel<{m},{d},rollout,jax> ({b} games x {EPISODE} steps per launch, two lanes per game)",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": int(b * bytes_step * steps_per_launch),
-                "mean_launch_us": launch_s * 1e6,
-                "note": "algorithmic = 501 B/env-step (SURVEY 8d) x games x steps; the fused kernel keeps the "
-                        "state in registers between steps, so real HBM traffic per launch is ~2*240 B/game",
-            },
+            "roofline": roofline,
             "games_finished_per_episode": finished,
         }
-        if single is not None:
-            out["single_step"] = single
-        if api is not None:
-            out["boundary_step"] = api
-        if large is not None:
-            out["large_batch"] = large
-        if legal is not None:
-            out["legal_axis_torch_list_semantics"] = legal
-        if config3 is not None:
-            out["config3_dim4_50points"] = config3
+        for key, val in (("single_step", single), ("boundary_step", api), ("single_step_dense", dense),
+                         ("large_batch", large), ("legal_axis_torch_list_semantics", legal),
+                         ("config3_dim4_50points", config3), ("config5_mcts_simulate", config5)):
+            if val is not None:
+                out[key] = val
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline_array_formulation"] = cpu_array_baseline()
@@ -528,6 +565,53 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_baseline(seconds: float = 12.0):
+    """C/OpenMP oracle on the host cores: the same episodes (64k games x 20 steps), repeated
+    until `seconds` of CPU work were timed."""
+    from hironaka_amd import _abi as A
+    from oracle import c_oracle as CO
+    threads = CO.set_threads(0)
+    fresh = CO.generate_points(BATCH, MAX_POINTS, DIM, MAX_VALUE, 42)
+    stages = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON
+    CO.rollout(fresh[:4096], EPISODE, SEED, record=False, stages=stages)  # warm-up
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        CO.rollout(fresh, EPISODE, SEED, record=False, stages=stages)
+        done += BATCH * EPISODE
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{done // (BATCH * EPISODE)} episodes of {BATCH} games x {EPISODE} steps "
+                      f"({dt:.1f} s) with oracle/hironaka_oracle.c (scalar C + OpenMP, {threads} threads "
+                      f"on {os.cpu_count()} logical cores)"}
+
+
+def cpu_array_baseline(budget_s: float = 10.0):
+    """SURVEY 8(d) CPU path (i): the reference's own formulation of the step -- broadcast [B,m,m,d] difference
+    tensors, masks, any/all, as in _jax_ops.py / _torch_ops.py -- on torch-CPU with all cores
+    (oracle/torch_cpu_oracle.py), the headline batch, step by step until the budget is spent (at most one
+    episode)."""
+    import torch
+    from oracle import np_oracle as NO
+    from oracle import torch_cpu_oracle as TO
+    threads = torch.get_num_threads()
+    p = torch.from_numpy(NO.generate_points(BATCH, MAX_POINTS, DIM, MAX_VALUE, 42))
+    table = torch.from_numpy(NO.decode_table(DIM)).float()
+    TO.step(p[:4096], table[torch.zeros(4096, dtype=torch.long)], torch.zeros(4096, dtype=torch.long))  # warm-up
+    steps, spent = 0, 0.0
+    while steps < EPISODE and spent < budget_s:
+        cls, ax = NO.policy_actions(p.numpy(), steps, SEED, 0, NO.HOST_RANDOM, NO.AGENT_RANDOM)
+        coords, axis = table[torch.from_numpy(cls).long()], torch.from_numpy(ax).long()
+        t0 = time.perf_counter()
+        p = TO.step(p, coords, axis)
+        spent += time.perf_counter() - t0
+        steps += 1
+    return {"value": BATCH * steps / spent, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "os_cpu_count": os.cpu_count(), "torch_num_threads": threads,
+            "sample": f"the first {steps} steps of one episode of {BATCH} games ({spent:.1f} s) with "
+                      f"oracle/torch_cpu_oracle.py (torch CPU tensor ops, the reference's broadcast-tensor "
+                      f"formulation, {threads} threads)"}
 
 
 if __name__ == "__main__":

@@ -1,0 +1,116 @@
+"""HipTrainer (hironaka_amd/trainer_api.py): the reference's `JAXTrainer.simulate(key, role, use_mcts_policy,
+use_unified_tree)` / `compute_rho` / `validate` entry points over the HIP environment.  Shapes and sanity checks
+follow test/testJAXTrainer.py:36-66; BASELINE configs[4] (8192 games x 32 simulations x 20 moves) runs at size."""
+import numpy as np
+import pytest
+import torch
+
+from hironaka_amd import _abi as A
+from hironaka_amd import ops
+from hironaka_amd.functional import rollout_sanity_tests
+from hironaka_amd.rollout import select_sample_after_sim
+from hironaka_amd.trainer_api import CONFIG_KEYS, HipTrainer, standin_mlp
+
+pytestmark = pytest.mark.gpu
+
+CONFIG = {  # hironaka/jax/jax_config.yml / test/jax_config.yml, smaller search
+    "eval_batch_size": 64, "max_num_points": 20, "dimension": 3, "max_length_game": 20, "max_value": 20,
+    "max_grad_norm": 1.0, "scale_observation": True, "reposition": True, "gumbel_scale": 0.3, "use_cuda": True,
+    "version_string": "test", "net_type": "dense", "num_evaluations": 10, "num_evaluations_as_opponent": 4,
+    "eval_on_cpu": False, "max_num_considered_actions": 10, "discount": 0.99,
+}
+
+
+def make_trainer(**over):
+    cfg = dict(CONFIG, **{k: v for k, v in over.items() if k in CONFIG_KEYS})
+    m, d = cfg["max_num_points"], cfg["dimension"]
+    host_net, host_params = standin_mlp(m * d, 2 ** d - d - 1, 3, width=64)
+    agent_net, agent_params = standin_mlp(m * d + d, d, 4, width=64)
+    return HipTrainer(42, cfg, host_net=host_net, agent_net=agent_net, host_params=host_params,
+                      agent_params=agent_params, use_graph=over.get("use_graph", False))
+
+
+def legal_successor(obs_t, obs_next, m, d):
+    """[B] bool: obs_next equals one HIP step (some host class, some axis) from obs_t -- the consecutive
+    observations of a rollout are one legal move apart"""
+    b = obs_t.shape[0]
+    pts = obs_t[:, : m * d].reshape(b, m, d).contiguous()
+    nxt = obs_next[:, : m * d].reshape(b, m, d)
+    ok = torch.zeros(b, dtype=torch.bool, device=obs_t.device)
+    stages = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON
+    for cls in range(2 ** d - d - 1):
+        c = torch.full((b,), cls, dtype=torch.int32, device=obs_t.device)
+        for axis in range(d):
+            a = torch.full((b,), axis, dtype=torch.int32, device=obs_t.device)
+            ok |= (ops.step(pts, c, a, stages=stages)["points"] == nxt).all(dim=2).all(dim=1)
+    return ok
+
+
+def test_config_keys_and_errors():
+    with pytest.raises(KeyError):
+        HipTrainer(0, {k: v for k, v in CONFIG.items() if k != "discount"}, host_net=lambda f, p: None,
+                   agent_net=lambda f, p: None)
+    with pytest.raises(TypeError):
+        HipTrainer(0, 3)
+    with pytest.raises(ValueError):
+        HipTrainer(0, CONFIG)
+    t = make_trainer()
+    assert t.input_dim == {"host": 60, "agent": 63} and t.output_dim == {"host": 4, "agent": 3}
+    with pytest.raises(ValueError):
+        t.simulate(0, "referee")
+
+
+@pytest.mark.parametrize("role", ["host", "agent"])
+def test_simulate_modes_shapes_and_sanity(role):
+    t = make_trainer()
+    b, T, m, d = t.eval_batch_size, t.max_length_game, t.max_num_points, t.dimension
+    for kw in ({}, {"use_unified_tree": True}, {"use_mcts_policy": True}):
+        obs, policy, value = exp = t.simulate(7, role, **kw)
+        unified = kw.get("use_unified_tree", False)
+        in_dim = (m + 1) * d if (unified or role == "agent") else m * d
+        acts = 2 ** d - d - 1 if (unified or role == "host") else d
+        assert obs.shape == (b * T, in_dim) and policy.shape == (b * T, acts) and value.shape == (b * T,)
+        assert rollout_sanity_tests(exp, (m, d))
+        assert torch.isfinite(value).all() and bool((value.abs() <= 1.0 + 1e-6).all())
+        if role == "agent" and not unified:
+            # every invalid agent action has probability 0 (test/testJAXTrainer.py:62)
+            assert bool((obs[:, -d:] - policy >= 0).all())
+        mask = select_sample_after_sim(role, exp, d, True, key=5)
+        assert mask.shape == (b * T,) and mask.dtype == torch.bool
+    # same key, same rollout (Philox-keyed states, deterministic networks, seeded gumbel noise)
+    again = t.simulate(7, role, use_mcts_policy=True)
+    assert all(torch.equal(torch.nan_to_num(x, neginf=-1e30), torch.nan_to_num(y, neginf=-1e30))
+               for x, y in zip(exp, again))
+
+
+def test_simulate_baseline_config5_at_size():
+    """BASELINE configs[4]: batch 8192, 32 simulations per move, 20 moves, dim 3, 20 points, one hipGraph per
+    search.  Checked: shapes, rollout_sanity_tests, value range, and that consecutive observations of every game are
+    ONE legal environment step apart (12 candidate moves tried per transition with hk_step)."""
+    t = make_trainer(eval_batch_size=8192, num_evaluations=32, use_graph=True)
+    b, T, m, d = 8192, t.max_length_game, t.max_num_points, t.dimension
+    obs, policy, value = exp = t.simulate(11, "host")
+    assert obs.shape == (b * T, m * d) and policy.shape == (b * T, 4) and value.shape == (b * T,)
+    assert rollout_sanity_tests(exp, (m, d))
+    assert bool((value.abs() <= 1.0 + 1e-6).all())
+    o = obs.reshape(b, T, m * d)
+    for step in (0, 1, 5, T - 2):
+        assert bool(legal_successor(o[:, step], o[:, step + 1], m, d).all()), step
+    # values of finished games are the discounted ground truth: +0.99^k
+    n_pts = (o >= 0).sum(dim=-1) // d
+    finished = n_pts[:, -1] <= 1
+    assert finished.any()
+    v = value.reshape(b, T)
+    assert bool((v[finished] > 0).all())
+
+
+def test_compute_rho_and_validate():
+    t = make_trainer()
+    rho, details = t.compute_rho("random", "random", batch_size=512, num_of_loops=2, max_length=12, key=9)
+    assert len(details) == 12 and sum(details) <= 1024 and 0 < rho < 1
+    # a network host against a fixed agent: the reference-shaped step loop
+    hosts, agents = t.get_cached_hosts_agents_for_validation(256)
+    rho2, det2 = t.compute_rho(hosts[0], agents[2], batch_size=256, num_of_loops=1, max_length=8, key=3)
+    assert len(det2) == 8 and sum(det2) <= 256
+    rhos, dets = t.validate(batch_size=128, num_of_loops=1, max_length=8, key=1)
+    assert len(rhos) == 7 and all(len(x) == 8 for x in dets)

@@ -468,3 +468,24 @@ def test_rollout_postprocess_reference_vectors():
         assert np.allclose(v.numpy(), want, rtol=0, atol=1e-6)
     with pytest.raises(ValueError):
         NO.rollout_postprocess(obs, dimension, discount, "referee", False)
+
+
+def test_torch_cpu_array_formulation_equals_numpy():
+    """oracle/torch_cpu_oracle.py (bench.py's all-core "reference CPU algorithm" leg) against np_oracle, bit for
+    bit: single steps on random holes / duplicates and a 12-step random-policy rollout."""
+    import torch
+    from oracle import torch_cpu_oracle as TO
+    rng = np.random.default_rng(5)
+    for m, d in ((20, 3), (10, 3), (12, 4)):
+        p = rng.integers(0, 6, (300, m, d)).astype(np.float32)
+        p[rng.random((300, m)) < 0.4] = -1.0
+        cls = rng.integers(0, 2 ** d - d - 1, 300)
+        ax = rng.integers(0, d, 300)
+        want = NO.step(p, NO.decode_class(cls, d), ax)
+        got = TO.step(torch.from_numpy(p), torch.from_numpy(NO.decode_class(cls, d)).float(),
+                      torch.from_numpy(ax)).numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    fresh = NO.generate_points(256, 20, 3, 20, 42)
+    want_p, want_rec = NO.rollout(fresh, 12, 7)
+    got_p, got_counts = TO.rollout(fresh, 12, 7)
+    assert np.array_equal(got_p, want_p) and np.array_equal(got_counts, want_rec["done_count"])
