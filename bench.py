@@ -154,7 +154,7 @@ def main():
             fn()  # eager first: allocations and lazy initialisation happen outside the capture
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=side):  # the stream of the eager call: per-stream workspaces exist
                 fn()
         torch.cuda.synchronize()
         return g

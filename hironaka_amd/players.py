@@ -26,7 +26,7 @@ def _generator(key: Key, device) -> Optional[torch.Generator]:
     if key is None or isinstance(key, torch.Generator):
         return key
     g = torch.Generator(device=device)
-    g.manual_seed(int(key))
+    g.manual_seed(int(key) % (1 << 63))
     return g
 
 

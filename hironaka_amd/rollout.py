@@ -97,10 +97,10 @@ def compute_rho(host: Union[str, Callable], agent: Union[str, Callable], *, spec
         counts[0] = get_dones(pts).sum()
         flat = flatten(pts)
         for step in range(max_length - 1):
-            host_action = host(flat, key=key * 7919 + loop * 131 + 2 * step)
+            host_action = host(flat, key=(key * 7919 + loop * 131 + 2 * step) % (1 << 62))
             coords = batch_decode(host_action, dtype)
             agent_obs = make_agent_obs(flat, coords)
-            axis = torch.argmax(agent(agent_obs, key=key * 7919 + loop * 131 + 2 * step + 1), dim=-1)
+            axis = torch.argmax(agent(agent_obs, key=(key * 7919 + loop * 131 + 2 * step + 1) % (1 << 62)), dim=-1)
             flat = take_action(flat, coords, axis)
             counts[step + 1] = get_dones(flat.reshape(-1, m, d)).sum()
         totals = counts.clone() if totals is None else totals + counts

@@ -214,7 +214,7 @@ class HipTrainer:
         unified_sim_fn = get_simulation("host", unified_eval_loop_with_gumbel, **simulation_config)
         mcts_policy_fn = mcts_wrapper(eval_loop_as_opp)
         if role == "agent":
-            mcts_policy_fn = apply_agent_action_mask(mcts_policy_fn, self.dimension)
+            mcts_policy_fn = apply_agent_action_mask(mcts_policy_fn, self.dimension, nan_free=True)
         if return_function:
             return eval_loop, eval_loop_as_opp, sim_fn, mcts_policy_fn, unified_eval_loop, unified_sim_fn
         setattr(self, f"{role}_eval_loop", eval_loop)
@@ -226,11 +226,14 @@ class HipTrainer:
         setattr(self, f"{role}_mcts_sim_fn", None)
 
     def update_policy_fn(self, role: str, return_function=False) -> Any:
-        """jax_trainer.py:836-855: feature function + network; the agent's logits go through its action mask"""
+        """jax_trainer.py:836-855: feature function + network; the agent's logits go through its action mask.
+        (The mask keeps the allowed logits: the reference's expression `policy * mask - inf * (~mask)`,
+        jax/util.py:302, evaluates inf * 0 = NaN on them -- functional.apply_agent_action_mask reproduces that
+        by default and documents it; a trainer cannot work with NaN logits.)"""
         policy_fn = get_apply_fn(role, getattr(self, f"{role}_model"), (self.max_num_points, self.dimension),
                                  feature_fn=getattr(self, f"{role}_feature_fn"))
         if role == "agent":
-            policy_fn = apply_agent_action_mask(policy_fn, self.dimension)
+            policy_fn = apply_agent_action_mask(policy_fn, self.dimension, nan_free=True)
         if return_function:
             return policy_fn
         setattr(self, f"{role}_policy_fn", policy_fn)

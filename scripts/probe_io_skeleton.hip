@@ -1,0 +1,156 @@
+// Dev probe (not part of the product): what does the I/O skeleton of hk_step cost at 65 536 games of 240 B,
+// before any game logic?  Variants of "slab in -> LDS image -> per-lane rows -> LDS -> slab out" over launch
+// geometry (games per wave, waves per workgroup) and a synthetic dependent-VALU chain of N instructions per lane
+// standing in for the step's work.  Build + run on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/probe_io scripts/probe_io_skeleton.hip && /tmp/probe_io
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+typedef float vf4 __attribute__((ext_vector_type(4)));
+constexpr int N = 60;       // floats per game
+constexpr int Q = N / 4;    // 16-B chunks per game
+
+// A: plain copy, CH chunks per lane, coalesced
+template <int CH, int TPB>
+__global__ __launch_bounds__(TPB) void copy_kernel(const vf4* __restrict__ in, vf4* __restrict__ out, int total) {
+  const int base = (blockIdx.x * TPB) * CH + threadIdx.x;
+  vf4 v[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) { int q = base + i * TPB; q = q < total ? q : total - 1; v[i] = in[q]; }
+#pragma unroll
+  for (int i = 0; i < CH; ++i) asm volatile("" : "+v"(v[i]));
+#pragma unroll
+  for (int i = 0; i < CH; ++i) { int q = base + i * TPB; if (q < total) out[q] = v[i]; }
+}
+
+// B: G games per wave (L = 64 / G lanes per game), WPB waves per workgroup (each wave its own LDS region, no
+// workgroup barrier), slab -> LDS -> each lane reads its share of the game's rows -> CHAIN dependent VALU ops ->
+// writes them back -> slab out
+template <int G, int WPB, int CHAIN>
+__global__ __launch_bounds__(64 * WPB) void skeleton_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            int batch) {
+  constexpr int L = 64 / G;             // lanes per game
+  constexpr int QW = (G * Q + 63) / 64;  // chunks per lane
+  constexpr int SH = N / L;             // floats per lane of its game (N divisible by L for L = 1, 2, 4)
+  __shared__ __align__(16) float lds_all[WPB * G * N];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* lds = lds_all + wave * G * N;
+  const long g0 = ((long)blockIdx.x * WPB + wave) * G;
+  if (g0 >= batch) return;
+  const int total = G * Q;
+  const vf4* src = reinterpret_cast<const vf4*>(in + g0 * N);
+  vf4 v[QW];
+#pragma unroll
+  for (int i = 0; i < QW; ++i) { int q = lane + i * 64; q = q < total ? q : total - 1; v[i] = src[q]; }
+#pragma unroll
+  for (int i = 0; i < QW; ++i) asm volatile("" : "+v"(v[i]));
+#pragma unroll
+  for (int i = 0; i < QW; ++i) { int q = lane + i * 64; if (q < total) *reinterpret_cast<vf4*>(lds + q * 4) = v[i]; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float* mine = lds + (lane / L) * N + (lane % L) * SH;
+  float r[SH];
+#pragma unroll
+  for (int k = 0; k < SH; ++k) r[k] = mine[k];
+  float acc = r[0];
+#pragma unroll 8
+  for (int c = 0; c < CHAIN; ++c) acc = acc * 1.0000001f + r[c % SH];
+  r[0] = (acc == 12345.678f) ? 0.0f : r[0];  // keeps the chain alive, never true in practice
+#pragma unroll
+  for (int k = 0; k < SH; ++k) mine[k] = r[k];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  vf4* dst = reinterpret_cast<vf4*>(out + g0 * N);
+#pragma unroll
+  for (int i = 0; i < QW; ++i) { int q = lane + i * 64; q = q < total ? q : total - 1; v[i] = *reinterpret_cast<const vf4*>(lds + q * 4); }
+#pragma unroll
+  for (int i = 0; i < QW; ++i) asm volatile("" : "+v"(v[i]));
+#pragma unroll
+  for (int i = 0; i < QW; ++i) { int q = lane + i * 64; if (q < total) dst[q] = v[i]; }
+}
+
+template <typename F>
+float time_us(F launch, float* a, float* b) {
+  hipStream_t s;
+  CK(hipStreamCreate(&s));
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+  for (int i = 0; i < 20; ++i) launch(s, (i & 1) ? b : a, (i & 1) ? a : b);
+  CK(hipStreamEndCapture(s, &graph));
+  CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 50; ++i) CK(hipGraphLaunch(exec, s));
+  CK(hipStreamSynchronize(s));
+  std::vector<float> t;
+  for (int rep = 0; rep < 7; ++rep) {
+    CK(hipEventRecord(e0, s));
+    for (int i = 0; i < 100; ++i) CK(hipGraphLaunch(exec, s));
+    CK(hipEventRecord(e1, s));
+    CK(hipStreamSynchronize(s));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    t.push_back(ms * 1e3f / 2000.0f);
+  }
+  std::sort(t.begin(), t.end());
+  CK(hipGraphExecDestroy(exec));
+  CK(hipGraphDestroy(graph));
+  CK(hipStreamDestroy(s));
+  return t[t.size() / 2];
+}
+
+template <int CH, int TPB>
+void run_copy(float* a, float* b, int batch) {
+  const int total = batch * Q;
+  const int grid = (total + CH * TPB - 1) / (CH * TPB);
+  float us = time_us([&](hipStream_t s, float* i, float* o) {
+    hipLaunchKernelGGL((copy_kernel<CH, TPB>), dim3(grid), dim3(TPB), 0, s, (const vf4*)i, (vf4*)o, total); }, a, b);
+  printf("copy      chunks/lane %2d  threads/wg %4d  grid %6d : %6.2f us\n", CH, TPB, grid, us);
+}
+
+template <int G, int WPB, int CHAIN>
+void run_skel(float* a, float* b, int batch) {
+  const int grid = (batch + G * WPB - 1) / (G * WPB);
+  float us = time_us([&](hipStream_t s, float* i, float* o) {
+    hipLaunchKernelGGL((skeleton_kernel<G, WPB, CHAIN>), dim3(grid), dim3(64 * WPB), 0, s, (const float*)i, o, batch); }, a, b);
+  printf("skeleton  games/wave %2d  waves/wg %d  chain %4d  grid %6d : %6.2f us\n", G, WPB, CHAIN, grid, us);
+}
+
+int main(int argc, char** argv) {
+  const int batch = argc > 1 ? atoi(argv[1]) : 65536;
+  float *a, *b;
+  CK(hipMalloc(&a, (size_t)batch * N * 4));
+  CK(hipMalloc(&b, (size_t)batch * N * 4));
+  CK(hipMemset(a, 0, (size_t)batch * N * 4));
+  CK(hipMemset(b, 0, (size_t)batch * N * 4));
+  printf("batch %d games x %d B\n", batch, N * 4);
+  run_copy<1, 256>(a, b, batch);
+  run_copy<4, 256>(a, b, batch);
+  run_copy<8, 64>(a, b, batch);
+  run_copy<8, 256>(a, b, batch);
+  run_copy<15, 64>(a, b, batch);
+  run_skel<64, 1, 0>(a, b, batch);
+  run_skel<32, 1, 0>(a, b, batch);
+  run_skel<16, 1, 0>(a, b, batch);
+  run_skel<32, 4, 0>(a, b, batch);
+  run_skel<16, 4, 0>(a, b, batch);
+  run_skel<16, 8, 0>(a, b, batch);
+  run_skel<64, 1, 1000>(a, b, batch);
+  run_skel<32, 1, 500>(a, b, batch);
+  run_skel<16, 1, 250>(a, b, batch);
+  run_skel<32, 4, 500>(a, b, batch);
+  run_skel<16, 4, 250>(a, b, batch);
+  run_skel<32, 1, 1000>(a, b, batch);
+  run_skel<16, 1, 500>(a, b, batch);
+  run_skel<16, 4, 500>(a, b, batch);
+  return 0;
+}

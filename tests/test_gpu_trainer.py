@@ -98,7 +98,7 @@ def test_simulate_baseline_config5_at_size():
         assert bool(legal_successor(o[:, step], o[:, step + 1], m, d).all()), step
     # values of finished games are the discounted ground truth: +0.99^k
     n_pts = (o >= 0).sum(dim=-1) // d
-    finished = n_pts[:, -1] <= 1
+    finished = (n_pts[:, -1] <= 1) & (n_pts[:, 0] > 1)  # (a game that starts finished earns nothing)
     assert finished.any()
     v = value.reshape(b, T)
     assert bool((v[finished] > 0).all())
