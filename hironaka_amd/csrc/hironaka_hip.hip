@@ -3,6 +3,7 @@
 // status code.  gfx950 only.
 #include "hk_fast_kernel.h"
 #include "hk_duo_kernel.h"
+#include "hk_quad_kernel.h"
 #include "hk_team_kernel.h"
 #include "hk_search.h"
 #include "hk_generic_kernel.h"
@@ -62,11 +63,27 @@ int launch_generic(Params& prm, int dtype, hipStream_t stream) {
 // kernel selection: register-resident specialisation -> team kernel (f32, dim 2..6, <= 64 rows; also the
 // specialised shapes on HK_FLAG_FORCE_TEAM) -> generic kernel (anything else: f64, dim > 6, > 64 rows,
 // HK_FLAG_FORCE_GENERIC, and the few mode / semantics combinations fast_supported / team_supported decline)
-constexpr unsigned kHostSideFlags = HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES;  // kernel selection only
+constexpr unsigned kHostSideFlags =
+    HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES | HK_FLAG_FORCE_FOUR_LANES;  // kernel selection only
+
+// hk_step on four lanes per game (hk_quad_kernel.h): where it is ahead of the two-lane kernel
+static bool use_quad(const Params& prm, int dtype) {
+  if (prm.flags & HK_FLAG_FORCE_FOUR_LANES) {
+    Params probe = prm;
+    probe.flags &= ~kHostSideFlags;
+    return quad_supported(probe, dtype);
+  }
+  if (!quad_supported(prm, dtype)) return false;
+  return quad_default(prm);
+}
 static bool use_duo(const Params& prm) { return !(prm.flags & HK_FLAG_FORCE_ONE_LANE) && duo_wanted(prm); }
 
 int launch(Params& prm, int dtype, hipStream_t stream) {
   if (prm.batch == 0) return HK_OK;
+  if (use_quad(prm, dtype)) {
+    prm.flags &= ~kHostSideFlags;
+    return launch_quad(prm, stream);
+  }
   if (fast_supported(prm, dtype)) {
     const bool duo = use_duo(prm);
     prm.flags &= ~kHostSideFlags;  // (the compiled rollout configurations compare flags)

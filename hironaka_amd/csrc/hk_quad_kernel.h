@@ -174,6 +174,22 @@ __device__ __forceinline__ void qd_rescale(float (&q)[R * D], unsigned flags) {
   }
 }
 
+// t = max_k(a - b), u = min_k(a - b).  The differences are results of a subtraction (canonical), so the plain
+// fmaxf / fminf chains become v_max3_f32 / v_min3_f32 without the canonicalising v_max x, x that loaded values get.
+template <int D>
+__device__ __forceinline__ void qd_extrema(const float* a, const float* b, float& t, float& u) {
+  float dk[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) dk[k] = a[k] - b[k];
+  t = dk[0];
+  u = dk[0];
+#pragma unroll
+  for (int k = 1; k < D; ++k) {
+    t = __builtin_fmaxf(t, dk[k]);
+    u = __builtin_fminf(u, dk[k]);
+  }
+}
+
 // One pair (mine, other) with t = max_k(mine - other), u = min_k(mine - other) (see d_newton in hk_duo_kernel.h):
 //   mine earlier:  other removed iff t <= 0;            mine removed iff u >= 0 and t > 0
 //   other earlier: other removed iff t <= 0 and u < 0;  mine removed iff u >= 0
@@ -182,7 +198,7 @@ __device__ __forceinline__ void qd_rescale(float (&q)[R * D], unsigned flags) {
 template <int D, int ORDER>
 __device__ __forceinline__ void qd_pair(const float* mine, const float* other, float& acc, float& oth, bool late) {
   float t, u;
-  diff_extrema<D>(mine, other, t, u);
+  qd_extrema<D>(mine, other, t, u);
   if (ORDER > 0) {
     oth = hk_fmin(oth, t);
     acc = hk_fmin(acc, (t > 0.0f) ? -u : 1.0f);
@@ -209,7 +225,7 @@ __device__ __forceinline__ void qd_newton(float (&q)[R * D], int j) {
 #pragma unroll
     for (int b = a + 1; b < NB; ++b) {
       float t, u;
-      diff_extrema<D>(&q[a * D], &q[b * D], t, u);
+      qd_extrema<D>(&q[a * D], &q[b * D], t, u);
       acc[b] = hk_fmin(acc[b], t);
       acc[a] = hk_fmin(acc[a], (t > 0.0f) ? -u : 1.0f);
     }
@@ -276,9 +292,90 @@ struct QuadStagesFor {
   }
 };
 
+// ---- the caller's actions ----------------------------------------------------------------------------------------
+// ACT: the layout of (coords, axis) as a compile-time fact, for the layouts the trainers use.  The run-time version
+// (kActAny: fetch_raw / scalar_from_raw, any dtype through double) costs ~0.9 us of a 7.5 us launch at 65 536 games:
+// 64-bit address arithmetic per value and a dtype switch per value in front of the slab's commit.
+enum QuadAct : int {
+  kActAny = 0,
+  kActMaskF32AxisI32 = 1,  // [B, d] float32 multi-binary mask (contiguous) + int32 axis: bench.py, get_take_actions
+  kActMaskF32AxisI64 = 2,  // ... + int64 axis: torch.argmax of the opponent's one-hot (recurrent_fn.py)
+  kActMaskF32AxisF32 = 3,  // ... + float32 axis: the JAX trainer's arrays (jax_trainer.py:528)
+  kActClassI32AxisI32 = 4  // [B] int32 class ids + int32 axis: the gym / list surface
+};
+
+inline int quad_act_of(const Params& prm) {
+  if (!(prm.stages & HK_STAGE_SHIFT)) return kActAny;
+  if (prm.coords_kind == HK_F32 && prm.coords_stride == prm.d) {
+    if (prm.axis_dtype == HK_I32) return kActMaskF32AxisI32;
+    if (prm.axis_dtype == HK_I64) return kActMaskF32AxisI64;
+    if (prm.axis_dtype == HK_F32) return kActMaskF32AxisF32;
+  }
+  if (prm.coords_kind == HK_COORDS_CLASS_I32 && prm.axis_dtype == HK_I32) return kActClassI32AxisI32;
+  return kActAny;
+}
+
+// One load per lane and value: lane j of the quad fetches coordinate min(j, D-1) of its game's mask (the four lanes of
+// a quad read consecutive dwords: the wave's request is dense), every lane the game's axis; the quad then hands the
+// coordinates round with DPP broadcasts.  Issued right behind the slab's requests, consumed after its commit.
+template <int D, int ACT>
+struct QuadActions {
+  uint32_t cword, aword, aword_hi;
+  RawActions<D> raw;  // kActAny only
+};
+
+template <int D, int ACT>
+__device__ __forceinline__ void quad_actions_issue(QuadActions<D, ACT>& a, const Params& prm, int64_t g, int m, int j) {
+  static_assert(D <= kQuad || ACT == kActAny || ACT == kActClassI32AxisI32, "mask broadcast needs dim <= 4");
+  if constexpr (ACT == kActAny) {
+    fast_fetch_actions<D>(prm, g, m, a.raw);
+  } else {
+    if constexpr (ACT == kActClassI32AxisI32) a.cword = ((const uint32_t*)prm.coords)[g];
+    else a.cword = ((const uint32_t*)prm.coords)[g * D + (j < D ? j : D - 1)];
+    if constexpr (ACT == kActMaskF32AxisI64) {
+      a.aword = ((const uint32_t*)prm.axis)[2 * g];
+      a.aword_hi = ((const uint32_t*)prm.axis)[2 * g + 1];
+    } else {
+      a.aword = ((const uint32_t*)prm.axis)[g];
+    }
+  }
+}
+
+template <int D, int ACT>
+__device__ __forceinline__ void quad_actions_decode(const QuadActions<D, ACT>& a, const Params& prm, float (&c)[D],
+                                                    int& axis) {
+  if constexpr (ACT == kActAny) {
+    fast_decode_actions<D>(prm, a.raw, c, axis);
+  } else {
+    if constexpr (ACT == kActClassI32AxisI32) {
+      constexpr int ncls = (1 << D) - D - 1;
+      int cls = (int)a.cword;
+      cls = cls < 0 ? 0 : (cls >= ncls ? ncls - 1 : cls);
+      const uint32_t v = decode_class(cls, D);
+#pragma unroll
+      for (int k = 0; k < D; ++k) c[k] = (float)((v >> k) & 1u);
+    } else {
+      // quad_perm [k, k, k, k]: coordinate k sits in lane k of the quad
+      c[0] = __int_as_float(qperm_i<0x00>((int)a.cword));
+      if constexpr (D > 1) c[D > 1 ? 1 : 0] = __int_as_float(qperm_i<0x55>((int)a.cword));
+      if constexpr (D > 2) c[D > 2 ? 2 : 0] = __int_as_float(qperm_i<0xAA>((int)a.cword));
+      if constexpr (D > 3) c[D > 3 ? 3 : 0] = __int_as_float(qperm_i<0xFF>((int)a.cword));
+    }
+    if constexpr (ACT == kActMaskF32AxisF32) {
+      const float f = __uint_as_float(a.aword);  // `arange(d) == axis`: non-integral / out-of-range match nothing
+      const int i = (int)f;
+      axis = (f >= 0.0f && f < (float)D && (float)i == f) ? i : -1;
+    } else if constexpr (ACT == kActMaskF32AxisI64) {
+      axis = (a.aword_hi == 0u && a.aword < (uint32_t)D) ? (int)a.aword : -1;
+    } else {
+      axis = (a.aword < (uint32_t)D) ? (int)a.aword : -1;
+    }
+  }
+}
+
 // ---- the kernel: single steps with the caller's actions (hk_step) -----------------------------------------------
 // HOT: kHotJax = the JAX trainer's take_actions (shift + reposition + Newton polytope, JAX semantics) compiled in.
-template <int M, int D, int HOT, int WPB>
+template <int M, int D, int HOT, int WPB, int ACT>
 __global__ __launch_bounds__(kWave * WPB) void quad_kernel(const float* in0, int64_t in_stride0, int batch0,
                                                            const Params prm) {
   using G = QuadGeom<M, D>;
@@ -308,12 +405,19 @@ __global__ __launch_bounds__(kWave * WPB) void quad_kernel(const float* in0, int
   int axis_in = -1;
 #pragma unroll
   for (int k = 0; k < D; ++k) c[k] = 0.0f;
-  RawActions<D> raw;
+  QuadActions<D, ACT> actions;
   const bool fetch_actions = (stages & HK_STAGE_SHIFT) && active;
-  if (fetch_actions) fast_fetch_actions<D>(prm, g, M, raw);
+  if (fetch_actions) quad_actions_issue<D, ACT>(actions, prm, g, M, j);
   quad_slab_commit<M, D>(slab, image, ngames, lane);
-  if (fetch_actions) fast_decode_actions<D>(prm, raw, c, axis_in);
+  if (fetch_actions) quad_actions_decode<D, ACT>(actions, prm, c, axis_in);
   wave_lds_fence();
+#ifdef HK_QUAD_PROBE  // dev builds only (scripts/build_probe.sh): stop after a phase to see what each one costs
+  const int cut = prm.lds_stride;
+  if (cut == 1) {
+    quad_slab_store<M, D>(image, (float*)prm.out + g0 * G::N, ngames, lane);
+    return;
+  }
+#endif
 
   // ---- live rows + exactness guard: lane j looks at rows j*R .. j*R + R - 1 -----------------------------------------
   float rows[R * D];
@@ -355,6 +459,13 @@ __global__ __launch_bounds__(kWave * WPB) void quad_kernel(const float* in0, int
   }
   int np = mask_pop(gmask);
   const bool exact = (fill == pad) && !__any(bad != 0);
+#ifdef HK_QUAD_PROBE
+  if (cut == 2) {
+    if (leader && prm.num_points_out) prm.num_points_out[g] = np + below + (exact ? 1 : 0);
+    quad_slab_store<M, D>(image, (float*)prm.out + g0 * G::N, ngames, lane);
+    return;
+  }
+#endif
 
   if (!exact) {
     // ---- slow path (whole wave): the quad's first lane runs the exact generic routines on the image -----------------
@@ -376,26 +487,30 @@ __global__ __launch_bounds__(kWave * WPB) void quad_kernel(const float* in0, int
     return;
   }
 
-  // ---- every live row to the slot of its rank in the compact image, tagged with its original index ---------------
+  // ---- every row to a slot of the compact image, tagged with its original index: a live row to its RANK among the
+  // live rows, a dead one behind them (np + its rank among the dead) -- a permutation, so every write is
+  // unconditional
   float* cmine = compact + gi * (M * G::CW);
   {
     int rank = below;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
+      const int i = i0 + r;
       const bool live = (lmask >> r) & 1u;
-      if (live) {
-        float* dst = cmine + rank * G::CW;
+      const int slot = live ? rank : np + i - rank;
+      if (M % kQuad == 0 || i < M) {  // (rows past M exist only in the last lane's tail when 4 does not divide M)
+        float* dst = cmine + slot * G::CW;
         if constexpr (D <= 3) {
           vf4 v;
           v.x = rows[r * D];
           v.y = D > 1 ? rows[r * D + (D > 1 ? 1 : 0)] : 0.0f;
           v.z = D > 2 ? rows[r * D + (D > 2 ? 2 : 0)] : 0.0f;
-          v.w = __int_as_float(i0 + r);
+          v.w = __int_as_float(i);
           *reinterpret_cast<vf4*>(dst) = v;
         } else {
 #pragma unroll
           for (int k = 0; k < D; ++k) dst[k] = rows[r * D + k];
-          dst[D] = __int_as_float(i0 + r);
+          dst[D] = __int_as_float(i);
         }
       }
       rank += live ? 1 : 0;
@@ -407,38 +522,40 @@ __global__ __launch_bounds__(kWave * WPB) void quad_kernel(const float* in0, int
   while (smax > 1 && !__any(np > kQuad * (smax - 1))) --smax;
   wave_lds_fence();
 
-  // ---- my slots: ranks j, j + 4, ... ----------------------------------------------------------------------------------
+  // ---- my slots: ranks j, j + 4, ... (all R of them are read: no exits, no exec juggling; slots past the game's
+  // live rows are holes) ---------------------------------------------------------------------------------------------
   float q[R * D];
   int orig[R];
 #pragma unroll
   for (int s = 0; s < R; ++s) {
-    orig[s] = 0;
-#pragma unroll
-    for (int k = 0; k < D; ++k) q[s * D + k] = INFINITY;
-  }
-  unrolled_while<0, R>([&](auto sc) {
-    constexpr int s = decltype(sc)::value;
-    if (s >= smax) return false;
     const bool has = kQuad * s + j < np;
-    const float* src = cmine + (has ? kQuad * s + j : 0) * G::CW;
+    const float* src = cmine + (kQuad * s + j < M ? kQuad * s + j : 0) * G::CW;
     if constexpr (D <= 3) {
       const vf4 v = *reinterpret_cast<const vf4*>(src);
       q[s * D] = has ? v.x : INFINITY;
       if (D > 1) q[s * D + (D > 1 ? 1 : 0)] = has ? v.y : INFINITY;
       if (D > 2) q[s * D + (D > 2 ? 2 : 0)] = has ? v.z : INFINITY;
-      orig[s] = has ? __float_as_int(v.w) : -1;
+      orig[s] = __float_as_int(v.w);
     } else {
 #pragma unroll
       for (int k = 0; k < D; ++k) {
         const float v = src[k];
         q[s * D + k] = has ? v : INFINITY;
       }
-      const int o = __float_as_int(src[D]);
-      orig[s] = has ? o : -1;
+      orig[s] = __float_as_int(src[D]);
     }
-    return true;
-  });
+  }
 
+#ifdef HK_QUAD_PROBE
+  if (cut == 3) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int e = 0; e < R * D; ++e) acc += (q[e] < INFINITY) ? q[e] : 0.0f;
+    if (leader && prm.reward_out) prm.reward_out[g] = acc + (float)orig[0];
+    quad_slab_store<M, D>(image, (float*)prm.out + g0 * G::N, ngames, lane);
+    return;
+  }
+#endif
   // ---- the transition -------------------------------------------------------------------------------------------------
   const bool prev_done = np < 2;
   np = QuadStagesFor<M, D, 1>::run(q, smax, c, axis_in, np, j, flags, stages);
@@ -450,11 +567,23 @@ __global__ __launch_bounds__(kWave * WPB) void quad_kernel(const float* in0, int
     if (prm.num_points_out) prm.num_points_out[g] = np;
   }
 
-  // ---- in place: every row that was live goes back to its slot, new coordinates or padding ---------------------------
+#ifdef HK_QUAD_PROBE
+  if (cut == 4) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int e = 0; e < R * D; ++e) acc += (q[e] < INFINITY) ? q[e] : 0.0f;
+    if (leader && prm.reward_out) prm.reward_out[g] = acc;
+    quad_slab_store<M, D>(image, (float*)prm.out + g0 * G::N, ngames, lane);
+    return;
+  }
+#endif
+  // ---- in place: the row of every slot in use goes back to its own place in the image -- new coordinates if it
+  // survived, padding if it was removed; the dead rows that sit in the slots past the live ones are padding already and
+  // are rewritten as such (unconditional writes) ------------------------------------------------------------------------
   unrolled_while<0, R>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
     if (s >= smax) return false;
-    if (orig[s] >= 0) {
+    if (M % kQuad == 0 || kQuad * s + j < M) {
       const bool removed = !(q[s * D] < INFINITY);
       float* dst = mine + orig[s] * D;
 #pragma unroll
@@ -474,20 +603,57 @@ constexpr int quad_waves_per_block() {
   return ((G::kImage + G::kCompact) * 4 * 4 <= 64 * 1024) ? 4 : 1;
 }
 
-template <int M, int D>
-int launch_quad_t(Params prm, hipStream_t stream) {
-  constexpr int WPB = quad_waves_per_block<M, D>();
+template <int M, int D, int WPB, int HOT, int ACT>
+void launch_quad_k(const Params& prm, unsigned grid, hipStream_t stream) {
+  size_t dynamic_lds = 0;
+#ifdef HK_QUAD_PROBE  // unused dynamic LDS: caps the workgroups per CU (how much does a second round of waves buy?)
+  const char* e = getenv("HK_QUAD_DLDS");
+  dynamic_lds = e ? (size_t)atoi(e) : 0;
+#endif
+  hipLaunchKernelGGL((quad_kernel<M, D, HOT, WPB, ACT>), dim3(grid), dim3(kWave * WPB), dynamic_lds, stream,
+                     (const float*)prm.in, prm.in_stride, prm.batch, prm);
+}
+
+template <int M, int D, int WPB>
+int launch_quad_w(Params prm, hipStream_t stream) {
   const int64_t waves = ((int64_t)prm.batch + kQuadGames - 1) / kQuadGames;
   const unsigned grid = (unsigned)((waves + WPB - 1) / WPB);
   prm.games_per_block = kQuadGames * WPB;
   launch_prepare();
-  if (prm.flags == HK_SEM_JAX && prm.stages == (HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON))
-    hipLaunchKernelGGL((quad_kernel<M, D, kHotJax, WPB>), dim3(grid), dim3(kWave * WPB), 0, stream,
-                       (const float*)prm.in, prm.in_stride, prm.batch, prm);
-  else
-    hipLaunchKernelGGL((quad_kernel<M, D, kHotNone, WPB>), dim3(grid), dim3(kWave * WPB), 0, stream,
-                       (const float*)prm.in, prm.in_stride, prm.batch, prm);
+  const bool hot = prm.flags == HK_SEM_JAX && prm.stages == (HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON);
+  const int act = quad_act_of(prm);
+  if (hot) {  // the JAX trainer's take_actions, with the trainers' action layouts compiled in
+    switch (act) {
+      case kActMaskF32AxisI32: launch_quad_k<M, D, WPB, kHotJax, kActMaskF32AxisI32>(prm, grid, stream); break;
+      case kActMaskF32AxisI64: launch_quad_k<M, D, WPB, kHotJax, kActMaskF32AxisI64>(prm, grid, stream); break;
+      case kActMaskF32AxisF32: launch_quad_k<M, D, WPB, kHotJax, kActMaskF32AxisF32>(prm, grid, stream); break;
+      case kActClassI32AxisI32: launch_quad_k<M, D, WPB, kHotJax, kActClassI32AxisI32>(prm, grid, stream); break;
+      default: launch_quad_k<M, D, WPB, kHotJax, kActAny>(prm, grid, stream);
+    }
+  } else if (act == kActClassI32AxisI32) {
+    launch_quad_k<M, D, WPB, kHotNone, kActClassI32AxisI32>(prm, grid, stream);
+  } else if (act == kActMaskF32AxisI64) {
+    launch_quad_k<M, D, WPB, kHotNone, kActMaskF32AxisI64>(prm, grid, stream);
+  } else {
+    launch_quad_k<M, D, WPB, kHotNone, kActAny>(prm, grid, stream);
+  }
   return launch_status();
+}
+
+template <int M, int D>
+int launch_quad_t(Params prm, hipStream_t stream) {
+#ifdef HK_QUAD_PROBE
+  const char* e = getenv("HK_QUAD_CUT");
+  prm.lds_stride = e ? atoi(e) : 0;
+  const char* w = getenv("HK_QUAD_WPB");
+  const int wpb = w ? atoi(w) : 0;
+  if constexpr (quad_waves_per_block<M, D>() > 1) {
+    if (wpb == 1) return launch_quad_w<M, D, 1>(prm, stream);
+    if (wpb == 2) return launch_quad_w<M, D, 2>(prm, stream);
+    if (wpb == 8) return launch_quad_w<M, D, 8>(prm, stream);
+  }
+#endif
+  return launch_quad_w<M, D, quad_waves_per_block<M, D>()>(prm, stream);
 }
 
 // (max_points, dim) with a four-lane step kernel
@@ -518,6 +684,12 @@ inline bool quad_supported(const Params& prm, int dtype) {
   HK_QUAD_SPECS(HK_X)
 #undef HK_X
   return false;
+}
+
+// where the four-lane kernel is the default choice (measured, scripts/probe_quad.py)
+inline bool quad_default(const Params& prm) {
+  if (prm.m * prm.d > 64) return false;  // (50,4): by HK_FLAG_FORCE_FOUR_LANES only, for now
+  return (int64_t)prm.batch * 2 <= (int64_t)3 * kWave * 1024;
 }
 
 #ifndef HK_SPEC_TU

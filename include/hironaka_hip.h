@@ -96,6 +96,8 @@ extern "C" {
 #define HK_FLAG_FORCE_ONE_LANE 256u     /* testing: one lane per game (hk::fast_kernel) where the launch would
                                          * otherwise deal a game's rows to two lanes (hk::duo_kernel)     */
 #define HK_FLAG_FORCE_TWO_LANES 512u    /* testing / tuning: two lanes per game (hk::duo_kernel) at any batch size */
+#define HK_FLAG_FORCE_FOUR_LANES 1024u  /* testing / tuning: four lanes per game (hk::quad_kernel) for every hk_step
+                                         * it can serve, at any batch size                                       */
 #define HK_FLAG_DEFER_COUNTS 128u       /* hk_rollout: leave the finished-game counts as partial
                                            sums in `workspace` (they accumulate over launches);
                                            hk_rollout_reduce_counts adds them to done_count     */

@@ -76,6 +76,42 @@ __global__ __launch_bounds__(64 * WPB) void skeleton_kernel(const float* __restr
   for (int i = 0; i < QW; ++i) { int q = lane + i * 64; if (q < total) dst[q] = v[i]; }
 }
 
+// C: every lane loads ITS OWN share of a game straight from HBM (BYTES contiguous bytes per lane, lane l at
+// l * BYTES: the wave still covers one contiguous piece) as 16-B requests (+ one shorter tail request), optionally
+// sends them through LDS (a stand-in for the compaction round trip), and stores them back the same way
+template <int BYTES, int TPB, bool VIA_LDS>
+__global__ __launch_bounds__(TPB) void rowwise_kernel(const float* __restrict__ in, float* __restrict__ out, long total_lanes) {
+  constexpr int NV = BYTES / 16, TAIL = (BYTES % 16) / 4;  // vf4 requests + tail dwords
+  __shared__ __align__(16) float lds[VIA_LDS ? TPB * (NV + 1) * 4 : 4];
+  const long l = (long)blockIdx.x * TPB + threadIdx.x;
+  if (l >= total_lanes) return;
+  const float* src = in + l * (BYTES / 4);
+  float* dst = out + l * (BYTES / 4);
+  vf4 v[NV];
+  float t[TAIL > 0 ? TAIL : 1];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const vf4*>(src + 4 * i);
+#pragma unroll
+  for (int i = 0; i < TAIL; ++i) t[i] = src[4 * NV + i];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(v[i]));
+  if (VIA_LDS) {
+    float* mine = lds + threadIdx.x * 4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) *reinterpret_cast<vf4*>(mine + i * TPB * 4) = v[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float* other = lds + (threadIdx.x ^ 1) * 4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const vf4*>(other + i * TPB * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) *reinterpret_cast<vf4*>(dst + 4 * i) = v[i];
+#pragma unroll
+  for (int i = 0; i < TAIL; ++i) dst[4 * NV + i] = t[i];
+}
+
 template <typename F>
 float time_us(F launch, float* a, float* b) {
   hipStream_t s;
@@ -125,6 +161,15 @@ void run_skel(float* a, float* b, int batch) {
   printf("skeleton  games/wave %2d  waves/wg %d  chain %4d  grid %6d : %6.2f us\n", G, WPB, CHAIN, grid, us);
 }
 
+template <int BYTES, int TPB, bool VIA_LDS>
+void run_rowwise(float* a, float* b, long bytes_total) {
+  const long lanes = bytes_total / BYTES;
+  const int grid = (int)((lanes + TPB - 1) / TPB);
+  float us = time_us([&](hipStream_t s, float* i, float* o) {
+    hipLaunchKernelGGL((rowwise_kernel<BYTES, TPB, VIA_LDS>), dim3(grid), dim3(TPB), 0, s, (const float*)i, o, lanes); }, a, b);
+  printf("rowwise   bytes/lane %3d  threads/wg %4d  via LDS %d  grid %6d : %6.2f us\n", BYTES, TPB, (int)VIA_LDS, grid, us);
+}
+
 int main(int argc, char** argv) {
   const int batch = argc > 1 ? atoi(argv[1]) : 65536;
   float *a, *b;
@@ -138,19 +183,18 @@ int main(int argc, char** argv) {
   run_copy<8, 64>(a, b, batch);
   run_copy<8, 256>(a, b, batch);
   run_copy<15, 64>(a, b, batch);
+  run_rowwise<60, 64, false>(a, b, (long)batch * N * 4);
+  run_rowwise<60, 256, false>(a, b, (long)batch * N * 4);
+  run_rowwise<60, 256, true>(a, b, (long)batch * N * 4);
+  run_rowwise<120, 256, false>(a, b, (long)batch * N * 4);
+  run_rowwise<48, 256, false>(a, b, (long)batch * N * 4);
+  run_rowwise<208, 64, false>(a, b, (long)batch * N * 4 / 208 * 208);
+  run_rowwise<208, 256, false>(a, b, (long)batch * N * 4 / 208 * 208);
   run_skel<64, 1, 0>(a, b, batch);
   run_skel<32, 1, 0>(a, b, batch);
   run_skel<16, 1, 0>(a, b, batch);
   run_skel<32, 4, 0>(a, b, batch);
   run_skel<16, 4, 0>(a, b, batch);
   run_skel<16, 8, 0>(a, b, batch);
-  run_skel<64, 1, 1000>(a, b, batch);
-  run_skel<32, 1, 500>(a, b, batch);
-  run_skel<16, 1, 250>(a, b, batch);
-  run_skel<32, 4, 500>(a, b, batch);
-  run_skel<16, 4, 250>(a, b, batch);
-  run_skel<32, 1, 1000>(a, b, batch);
-  run_skel<16, 1, 500>(a, b, batch);
-  run_skel<16, 4, 500>(a, b, batch);
   return 0;
 }

@@ -19,7 +19,7 @@ from hironaka_amd import _abi as A
 from hironaka_amd import ops
 from oracle import c_oracle as CO
 
-FAST = [(4, 3), (5, 3), (10, 3), (16, 3), (20, 3), (8, 4), (20, 4)]
+FAST = [(4, 3), (5, 3), (10, 3), (16, 3), (20, 3), (8, 4), (20, 4), (50, 4)]
 
 
 class Mismatch(AssertionError):
@@ -78,8 +78,8 @@ def one_case(rng):
     b = int(rng.choice([1, 15, 16, 17, 63, 64, 65, 200, 1000, 3000]))
     sem = ["jax", "torch", "list"][rng.integers(0, 3)]
     pad = float(rng.choice([-1.0, -1.0, -1.0, -1e-8, -2.5]))
-    force = int(rng.choice([0, 0, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_TEAM,
-                           A.HK_FLAG_FORCE_GENERIC]))
+    force = int(rng.choice([0, 0, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_TWO_LANES, A.HK_FLAG_FORCE_FOUR_LANES,
+                           A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC]))
     noop, ign = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     if rng.integers(0, 4) == 0:  # the flag sets of the compiled rollout configurations
         noop = ign = (sem == "torch")

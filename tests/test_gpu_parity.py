@@ -521,8 +521,11 @@ def test_error_behaviour():
 def test_ragged_batch_sizes(b):
     """batches that do not fill the last wave (or even one wave), every kernel family, step + rollout +
     generate; also checks nothing is written past the batch (guard rows after the tensors)."""
-    for (m, d), flag_sets in (((20, 3), (0, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC)),
-                              ((50, 4), (0, A.HK_FLAG_FORCE_GENERIC)), ((7, 5), (0, A.HK_FLAG_FORCE_GENERIC))):
+    for (m, d), flag_sets in (((20, 3), (0, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_TWO_LANES, A.HK_FLAG_FORCE_FOUR_LANES,
+                                        A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC)),
+                              ((10, 3), (0, A.HK_FLAG_FORCE_FOUR_LANES)),
+                              ((50, 4), (0, A.HK_FLAG_FORCE_FOUR_LANES, A.HK_FLAG_FORCE_GENERIC)),
+                              ((7, 5), (0, A.HK_FLAG_FORCE_GENERIC))):
         p0 = CO.generate_points(b, m, d, 20, 3, game_offset=9)
         rng = np.random.default_rng(b)
         cls = rng.integers(0, 2 ** d - d - 1, b).astype(np.int32)
