@@ -74,7 +74,7 @@ static bool use_quad(const Params& prm, int dtype) {
     return quad_supported(probe, dtype);
   }
   if (!quad_supported(prm, dtype)) return false;
-  return quad_default(prm);
+  return quad_default(prm, device_simds());
 }
 static bool use_duo(const Params& prm) { return !(prm.flags & HK_FLAG_FORCE_ONE_LANE) && duo_wanted(prm); }
 

@@ -60,65 +60,78 @@ struct QuadGeom {
   static constexpr int Q = N / W;                                      // chunks per game
   static constexpr int QL = (kQuadGames * Q + kWave - 1) / kWave;      // slab chunks per lane
   static constexpr int R = (M + kQuad - 1) / kQuad;                    // rows a lane scans = slots per lane
-  static constexpr int CW = (D <= 3) ? 4 : D + 1;                      // compact row: D coordinates + original index
+  // Large games ((50,4): 12.8 KB of image per wave) keep ONE region per wave: the compact image lies over the
+  // slab image (every lane has read its rows by then), without the index tag, and the result returns through the
+  // compact slots to the lane that owns each row, which rebuilds its part of the image.  Small games keep the two
+  // images apart and write the result back in place (fewer LDS operations).
+  static constexpr bool kBig = N * kQuadGames * 4 > 8 * 1024;
+  static constexpr int CW = kBig ? ((D <= 4) ? 4 : D) : ((D <= 3) ? 4 : D + 1);  // compact row (+ index tag when small)
   static constexpr int kImage = kQuadGames * N;                        // floats
-  static constexpr int kCompact = kQuadGames * M * CW;                 // floats
+  static constexpr int kCompact = kBig ? 0 : kQuadGames * M * CW;      // floats (kBig: aliased over the image)
+  static constexpr int kRegion = kBig ? kQuadGames * (N > M * CW ? N : M * CW) : kImage + kCompact;
+  static constexpr int kGameStride = kBig ? (N > M * CW ? N : M * CW) : N;  // floats between two games' images
+  static constexpr int kStoreBatch = QL < 12 ? QL : 10;                // slab chunks per store round
   // buckets of straight-line bodies (slots per lane)
   static constexpr int next_bucket(int nb) { return nb < 6 ? nb + 1 : (nb < 10 ? nb + 2 : nb + 3); }
+  static_assert(!kBig || kGameStride == N, "the aliased layout assumes the compact rows fit the image");
 };
 
 // ---- slab I/O: 16 consecutive games = one contiguous piece of HBM (contiguous records only: the dispatcher sends
 // strided records to the other kernels) ----------------------------------------------------------------------------
+// in: LDS-DMA (global_load_lds_dwordx4: lane l of request `it` moves 16 B to image + (it * 64 + l) * 16 -- the image
+// IS the slab, no registers, no ds_write); chunks past a partial slab re-read its last chunk into image space that
+// nobody looks at.  Completion is the wave's vmcnt.
 template <int M, int D>
-struct QuadSlab {
-  typename VecOf<QuadGeom<M, D>::W>::type v[QuadGeom<M, D>::QL];
-};
-
-template <int M, int D>
-__device__ __forceinline__ void quad_slab_issue(QuadSlab<M, D>& r, const float* base, int ngames, int lane) {
+__device__ __forceinline__ void quad_slab_load(const float* base, float* image, int ngames, int lane) {
   using G = QuadGeom<M, D>;
-  using V = typename VecOf<G::W>::type;
-  const int total = ngames * G::Q;
+  if constexpr (G::W == 4) {
+    const int total = ngames * G::Q;
 #pragma unroll
-  for (int it = 0; it < G::QL; ++it) {
-    int q = lane + it * kWave;
-    q = q < total ? q : total - 1;
-    r.v[it] = *reinterpret_cast<const V*>(base + (int64_t)q * G::W);
+    for (int it = 0; it < G::QL; ++it) {
+      int q = lane + it * kWave;
+      const bool inside = q < kQuadGames * G::Q;  // (the last request may reach past the image: those lanes sit out)
+      q = q < total ? q : total - 1;
+      if ((it + 1) * kWave <= kQuadGames * G::Q || inside)
+        __builtin_amdgcn_global_load_lds(base + (int64_t)q * 4, image + it * kWave * 4, 16, 0, 0);
+    }
+  } else {  // records that are no multiple of 16 B: dword requests
+    constexpr int QF = (kQuadGames * G::N + kWave - 1) / kWave;
+    const int total = ngames * G::N;
+#pragma unroll
+    for (int it = 0; it < QF; ++it) {
+      int q = lane + it * kWave;
+      const bool inside = q < kQuadGames * G::N;
+      q = q < total ? q : total - 1;
+      if ((it + 1) * kWave <= kQuadGames * G::N || inside)
+        __builtin_amdgcn_global_load_lds(base + q, image + it * kWave, 4, 0, 0);
+    }
   }
 }
 
-template <int M, int D>
-__device__ __forceinline__ void quad_slab_commit(QuadSlab<M, D>& r, float* image, int ngames, int lane) {
-  using G = QuadGeom<M, D>;
-  using V = typename VecOf<G::W>::type;
-  const int total = ngames * G::Q;
-#pragma unroll
-  for (int it = 0; it < G::QL; ++it) asm volatile("" : "+v"(r.v[it]));
-#pragma unroll
-  for (int it = 0; it < G::QL; ++it) {
-    const int q = lane + it * kWave;
-    if (q < total) *reinterpret_cast<V*>(image + q * G::W) = r.v[it];
-  }
-}
+__device__ __forceinline__ void wait_vmem_all() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0)
 
 template <int M, int D>
 __device__ __forceinline__ void quad_slab_store(const float* image, float* base, int ngames, int lane) {
   using G = QuadGeom<M, D>;
   using V = typename VecOf<G::W>::type;
+  constexpr int B = G::kStoreBatch;
   const int total = ngames * G::Q;
-  V v[G::QL];
 #pragma unroll
-  for (int it = 0; it < G::QL; ++it) {
-    int q = lane + it * kWave;
-    q = q < kQuadGames * G::Q ? q : kQuadGames * G::Q - 1;
-    v[it] = *reinterpret_cast<const V*>(image + q * G::W);
-  }
+  for (int i0 = 0; i0 < G::QL; i0 += B) {
+    V v[B];
 #pragma unroll
-  for (int it = 0; it < G::QL; ++it) asm volatile("" : "+v"(v[it]));
+    for (int u = 0; u < B; ++u) {
+      int q = lane + (i0 + u) * kWave;
+      q = q < kQuadGames * G::Q ? q : kQuadGames * G::Q - 1;
+      v[u] = *reinterpret_cast<const V*>(image + q * G::W);
+    }
 #pragma unroll
-  for (int it = 0; it < G::QL; ++it) {
-    const int q = lane + it * kWave;
-    if (q < total) *reinterpret_cast<V*>(base + (int64_t)q * G::W) = v[it];
+    for (int u = 0; u < B; ++u) asm volatile("" : "+v"(v[u]));
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+      const int q = lane + (i0 + u) * kWave;
+      if (i0 + u < G::QL && q < total) *reinterpret_cast<V*>(base + (int64_t)q * G::W) = v[u];
+    }
   }
 }
 
@@ -251,6 +264,8 @@ __device__ __forceinline__ void qd_newton(float (&q)[R * D], int j) {
       } else {
         qd_pair<D, -1>(&q[a * D], p1, acc[a], o1[b], true);
       }
+      // many registers per lane: one pair of tests at a time (the scheduler would interleave the whole row of them)
+      if constexpr (R * D > 32) __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -264,13 +279,93 @@ __device__ __forceinline__ void qd_newton(float (&q)[R * D], int j) {
   }
 }
 
+// The same test for MANY slots per lane (more than kQuadDppSlots: states that no Newton pass has thinned yet), as a
+// rolled loop over the game's rows through the compact image instead of 2 NB^2 unrolled pair tests: the quad parks
+// its rows at their ranks, then rows j = 4(c-1) .. 4c-1 (one broadcast read per j) meet the lane's slots 0 .. c-1,
+// i.e. the rows i < j only -- each unordered pair once, one set of differences for both directions:
+//     t = max_k(P_j - P_i), u = min_k(P_j - P_i);   j is removed by i iff u >= 0;   i by j iff t <= 0 and u < 0
+// (of two equal rows the later one goes).  Verdicts on the lane's own rows go to acc[]; those on row j, which another
+// lane owns, are bits of jmask, OR-ed over the quad afterwards.  The segment for c slots is straight-line in the slots.
+constexpr int kQuadDppSlots = 8;
+
+template <int CW, int R, int D, int NB, int CSEG>
+struct QuadLdsPairs {
+  static __device__ __forceinline__ void run(const float (&q)[R * D], float (&acc)[NB], uint32_t (&jmask)[2],
+                                             const float* cmine, int j, int rows_end) {
+    constexpr int r0 = kQuad * (CSEG - 1);
+    if (rows_end <= r0) return;
+    const int r1 = rows_end < kQuad * CSEG ? rows_end : kQuad * CSEG;
+#pragma nounroll
+    for (int row = r0; row < r1; ++row) {
+      float pj[D];
+      if constexpr (D == 4) {
+        const vf4 v = *reinterpret_cast<const vf4*>(cmine + row * CW);
+        pj[0] = v.x; pj[1] = v.y; pj[2] = v.z; pj[3] = v.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) pj[k] = cmine[row * CW + k];
+      }
+      bool jdead = false;
+#pragma unroll
+      for (int s = 0; s < CSEG; ++s) {
+        float t, u;
+        qd_extrema<D>(pj, &q[s * D], t, u);
+        const bool below = (s < CSEG - 1) || (r0 + j < row);  // my row 4s + j lies below row j
+        jdead |= below && (u >= 0.0f);
+        acc[s] = hk_fmin(acc[s], (below && u < 0.0f) ? t : 1.0f);
+      }
+      const uint32_t bit = jdead ? (1u << (row & 31)) : 0u;
+      if (row < 32) jmask[0] |= bit;
+      else jmask[1] |= bit;
+    }
+    if constexpr (CSEG < NB) QuadLdsPairs<CW, R, D, NB, CSEG + 1>::run(q, acc, jmask, cmine, j, rows_end);
+  }
+};
+
+template <int M, int CW, int R, int D, int NB>
+__device__ __forceinline__ void qd_newton_lds(float (&q)[R * D], float* cmine, int j, int rows_end) {
+  static_assert(kQuad * NB <= 64, "verdicts on row j travel as 64 bits");
+#pragma unroll
+  for (int s = 0; s < NB; ++s) {
+    if (kQuad * s + j < M) {
+      float* dst = cmine + (kQuad * s + j) * CW;
+      if constexpr (D == 4) {
+        *reinterpret_cast<vf4*>(dst) = vf4{q[s * D], q[s * D + 1], q[s * D + 2], q[s * D + 3]};
+      } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) dst[k] = q[s * D + k];
+      }
+    }
+  }
+  wave_lds_fence();
+  float acc[NB];
+#pragma unroll
+  for (int s = 0; s < NB; ++s) acc[s] = INFINITY;
+  uint32_t jmask[2] = {0u, 0u};
+  QuadLdsPairs<CW, R, D, NB, 1>::run(q, acc, jmask, cmine, j, rows_end);
+  jmask[0] = q_or(jmask[0]);
+  jmask[1] = q_or(jmask[1]);
+#pragma unroll
+  for (int s = 0; s < NB; ++s) {
+    const int i = kQuad * s + j;
+    const bool by_lower = ((i < 32 ? jmask[0] : jmask[1]) >> (i & 31)) & 1u;
+    const bool removed = acc[s] <= 0.0f || by_lower;  // (a hole stays a hole either way)
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[s * D + k] = removed ? INFINITY : q[s * D + k];
+  }
+  wave_lds_fence();  // the compact image is written again after the stages
+}
+
 // one transition on slots [0, NB) of the four lanes; returns the GAME's number of live rows
-template <int R, int D, int NB>
+template <int M, int CW, int R, int D, int NB>
 __device__ __forceinline__ int qd_stages(float (&q)[R * D], const float (&c)[D], int axis, int np, int j,
-                                         unsigned flags, unsigned stages) {
+                                         unsigned flags, unsigned stages, float* cmine, int slots_end) {
   if (stages & HK_STAGE_SHIFT) b_shift<R, D, NB>(q, c, axis, np, flags);
   if (stages & HK_STAGE_REPOSITION) qd_reposition<R, D, NB>(q, flags);
-  if (stages & HK_STAGE_NEWTON) qd_newton<R, D, NB>(q, j);
+  if (stages & HK_STAGE_NEWTON) {
+    if constexpr (NB > kQuadDppSlots) qd_newton_lds<M, CW, R, D, NB>(q, cmine, j, slots_end);
+    else qd_newton<R, D, NB>(q, j);
+  }
   if (stages & HK_STAGE_RESCALE) qd_rescale<R, D, NB>(q, flags);
   int n = 0;
 #pragma unroll
@@ -282,12 +377,13 @@ template <int M, int D, int NB>
 struct QuadStagesFor {
   using G = QuadGeom<M, D>;
   static __device__ __forceinline__ int run(float (&q)[G::R * D], int smax, const float (&c)[D], int axis, int np,
-                                            int j, unsigned flags, unsigned stages) {
+                                            int j, unsigned flags, unsigned stages, float* cmine) {
+    const int slots_end = kQuad * smax < M ? kQuad * smax : M;
     if constexpr (NB >= G::R) {
-      return qd_stages<G::R, D, G::R>(q, c, axis, np, j, flags, stages);
+      return qd_stages<M, G::CW, G::R, D, G::R>(q, c, axis, np, j, flags, stages, cmine, slots_end);
     } else {
-      if (smax <= NB) return qd_stages<G::R, D, NB>(q, c, axis, np, j, flags, stages);
-      return QuadStagesFor<M, D, G::next_bucket(NB)>::run(q, smax, c, axis, np, j, flags, stages);
+      if (smax <= NB) return qd_stages<M, G::CW, G::R, D, NB>(q, c, axis, np, j, flags, stages, cmine, slots_end);
+      return QuadStagesFor<M, D, G::next_bucket(NB)>::run(q, smax, c, axis, np, j, flags, stages, cmine);
     }
   }
 };
@@ -375,17 +471,18 @@ __device__ __forceinline__ void quad_actions_decode(const QuadActions<D, ACT>& a
 
 // ---- the kernel: single steps with the caller's actions (hk_step) -----------------------------------------------
 // HOT: kHotJax = the JAX trainer's take_actions (shift + reposition + Newton polytope, JAX semantics) compiled in.
+// register budget: four waves per SIMD (<= 128 VGPRs), three for the large games (<= 168; their LDS allows no more)
 template <int M, int D, int HOT, int WPB, int ACT>
-__global__ __launch_bounds__(kWave * WPB) void quad_kernel(const float* in0, int64_t in_stride0, int batch0,
+__global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kBig ? 2 : 4)) void quad_kernel(const float* in0, int64_t in_stride0, int batch0,
                                                            const Params prm) {
   using G = QuadGeom<M, D>;
   constexpr int R = G::R;
   using MaskM = MaskT<M>;
-  __shared__ __align__(16) float lds_all[WPB * (G::kImage + G::kCompact)];
+  __shared__ __align__(16) float lds_all[WPB * G::kRegion];
   __shared__ float cbuf_all[WPB * kQuadGames * D];  // slow path only
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
-  float* image = lds_all + wave * (G::kImage + G::kCompact);
-  float* compact = image + G::kImage;
+  float* image = lds_all + wave * G::kRegion;
+  float* compact = G::kBig ? image : image + G::kImage;
   const int j = lane & 3, gi = lane >> 2;
   const int64_t g0 = ((int64_t)blockIdx.x * WPB + wave) * kQuadGames;
   const int64_t left = (int64_t)batch0 - g0;
@@ -394,8 +491,7 @@ __global__ __launch_bounds__(kWave * WPB) void quad_kernel(const float* in0, int
   const bool active = gi < ngames;
   const bool leader = active && j == 0;
   const int64_t g = g0 + gi;
-  QuadSlab<M, D> slab;
-  quad_slab_issue<M, D>(slab, in0 + g0 * G::N, ngames, lane);
+  quad_slab_load<M, D>(in0 + g0 * G::N, image, ngames, lane);
   float* mine = image + gi * G::N;
   const float pad = (float)prm.pad;
   const unsigned flags = (HOT == kHotJax) ? (unsigned)HK_SEM_JAX : prm.flags;
@@ -408,7 +504,7 @@ __global__ __launch_bounds__(kWave * WPB) void quad_kernel(const float* in0, int
   QuadActions<D, ACT> actions;
   const bool fetch_actions = (stages & HK_STAGE_SHIFT) && active;
   if (fetch_actions) quad_actions_issue<D, ACT>(actions, prm, g, M, j);
-  quad_slab_commit<M, D>(slab, image, ngames, lane);
+  wait_vmem_all();
   if (fetch_actions) quad_actions_decode<D, ACT>(actions, prm, c, axis_in);
   wave_lds_fence();
 #ifdef HK_QUAD_PROBE  // dev builds only (scripts/build_probe.sh): stop after a phase to see what each one costs
@@ -423,9 +519,18 @@ __global__ __launch_bounds__(kWave * WPB) void quad_kernel(const float* in0, int
   float rows[R * D];
   const int i0 = j * R;
 #pragma unroll
-  for (int r = 0; r < R; ++r)
+  for (int r = 0; r < R; ++r) {
+    if constexpr (D == 4) {  // a row is one aligned 16-B read
+      const vf4 v = *reinterpret_cast<const vf4*>(mine + (i0 + r < M ? i0 + r : M - 1) * D);
+      rows[r * D] = (i0 + r < M) ? v.x : fill;
+      rows[r * D + 1] = (i0 + r < M) ? v.y : fill;
+      rows[r * D + 2] = (i0 + r < M) ? v.z : fill;
+      rows[r * D + 3] = (i0 + r < M) ? v.w : fill;
+    } else {
 #pragma unroll
-    for (int k = 0; k < D; ++k) rows[r * D + k] = (i0 + r < M) ? mine[(i0 + r) * D + k] : fill;
+      for (int k = 0; k < D; ++k) rows[r * D + k] = (i0 + r < M) ? mine[(i0 + r) * D + k] : fill;
+    }
+  }
   const uint32_t fill_bits = __float_as_uint(fill);
   uint32_t lmask = 0, bad = 0;
 #pragma unroll
@@ -487,30 +592,43 @@ __global__ __launch_bounds__(kWave * WPB) void quad_kernel(const float* in0, int
     return;
   }
 
-  // ---- every row to a slot of the compact image, tagged with its original index: a live row to its RANK among the
-  // live rows, a dead one behind them (np + its rank among the dead) -- a permutation, so every write is
-  // unconditional
-  float* cmine = compact + gi * (M * G::CW);
+  // ---- compaction.  Small games: EVERY row to a slot of the compact image, tagged with its original index -- a live
+  // row to its RANK among the live rows, a dead one behind them (np + its rank among the dead): a permutation, so
+  // every write is unconditional.  Large games (the compact image lies over the slab image, which every lane has
+  // read by now): the live rows only, no tag.
+  float* cmine = compact + gi * (G::kBig ? G::kGameStride : M * G::CW);
   {
     int rank = below;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int i = i0 + r;
       const bool live = (lmask >> r) & 1u;
-      const int slot = live ? rank : np + i - rank;
-      if (M % kQuad == 0 || i < M) {  // (rows past M exist only in the last lane's tail when 4 does not divide M)
-        float* dst = cmine + slot * G::CW;
-        if constexpr (D <= 3) {
-          vf4 v;
-          v.x = rows[r * D];
-          v.y = D > 1 ? rows[r * D + (D > 1 ? 1 : 0)] : 0.0f;
-          v.z = D > 2 ? rows[r * D + (D > 2 ? 2 : 0)] : 0.0f;
-          v.w = __int_as_float(i);
-          *reinterpret_cast<vf4*>(dst) = v;
-        } else {
+      if constexpr (G::kBig) {
+        if (live) {
+          float* dst = cmine + rank * G::CW;
+          if constexpr (D == 4) {
+            *reinterpret_cast<vf4*>(dst) = vf4{rows[r * D], rows[r * D + 1], rows[r * D + 2], rows[r * D + 3]};
+          } else {
 #pragma unroll
-          for (int k = 0; k < D; ++k) dst[k] = rows[r * D + k];
-          dst[D] = __int_as_float(i);
+            for (int k = 0; k < D; ++k) dst[k] = rows[r * D + k];
+          }
+        }
+      } else {
+        const int slot = live ? rank : np + i - rank;
+        if (M % kQuad == 0 || i < M) {  // (rows past M exist only in the last lane's tail when 4 does not divide M)
+          float* dst = cmine + slot * G::CW;
+          if constexpr (D <= 3) {
+            vf4 v;
+            v.x = rows[r * D];
+            v.y = D > 1 ? rows[r * D + (D > 1 ? 1 : 0)] : 0.0f;
+            v.z = D > 2 ? rows[r * D + (D > 2 ? 2 : 0)] : 0.0f;
+            v.w = __int_as_float(i);
+            *reinterpret_cast<vf4*>(dst) = v;
+          } else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) dst[k] = rows[r * D + k];
+            dst[D] = __int_as_float(i);
+          }
         }
       }
       rank += live ? 1 : 0;
@@ -522,15 +640,32 @@ __global__ __launch_bounds__(kWave * WPB) void quad_kernel(const float* in0, int
   while (smax > 1 && !__any(np > kQuad * (smax - 1))) --smax;
   wave_lds_fence();
 
-  // ---- my slots: ranks j, j + 4, ... (all R of them are read: no exits, no exec juggling; slots past the game's
-  // live rows are holes) ---------------------------------------------------------------------------------------------
+  // ---- my slots: ranks j, j + 4, ...; slots past the game's live rows are holes.  Small games read all R slots
+  // (no exits, no exec juggling); large ones stop at the wave's smax. ---------------------------------------------------
   float q[R * D];
-  int orig[R];
+  int orig[G::kBig ? 1 : R];
 #pragma unroll
-  for (int s = 0; s < R; ++s) {
+  for (int e = 0; e < R * D; ++e) q[e] = INFINITY;
+  unrolled_while<0, R>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (G::kBig && s >= smax) return false;
     const bool has = kQuad * s + j < np;
     const float* src = cmine + (kQuad * s + j < M ? kQuad * s + j : 0) * G::CW;
-    if constexpr (D <= 3) {
+    if constexpr (G::kBig) {
+      if constexpr (D == 4) {
+        const vf4 v = *reinterpret_cast<const vf4*>(src);
+        q[s * D] = has ? v.x : INFINITY;
+        q[s * D + 1] = has ? v.y : INFINITY;
+        q[s * D + 2] = has ? v.z : INFINITY;
+        q[s * D + 3] = has ? v.w : INFINITY;
+      } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const float v = src[k];
+          q[s * D + k] = has ? v : INFINITY;
+        }
+      }
+    } else if constexpr (D <= 3) {
       const vf4 v = *reinterpret_cast<const vf4*>(src);
       q[s * D] = has ? v.x : INFINITY;
       if (D > 1) q[s * D + (D > 1 ? 1 : 0)] = has ? v.y : INFINITY;
@@ -544,21 +679,23 @@ __global__ __launch_bounds__(kWave * WPB) void quad_kernel(const float* in0, int
       }
       orig[s] = __float_as_int(src[D]);
     }
-  }
+    return true;
+  });
 
 #ifdef HK_QUAD_PROBE
   if (cut == 3) {
     float acc = 0.0f;
 #pragma unroll
     for (int e = 0; e < R * D; ++e) acc += (q[e] < INFINITY) ? q[e] : 0.0f;
-    if (leader && prm.reward_out) prm.reward_out[g] = acc + (float)orig[0];
+    if (leader && prm.reward_out) prm.reward_out[g] = acc;
     quad_slab_store<M, D>(image, (float*)prm.out + g0 * G::N, ngames, lane);
     return;
   }
 #endif
   // ---- the transition -------------------------------------------------------------------------------------------------
   const bool prev_done = np < 2;
-  np = QuadStagesFor<M, D, 1>::run(q, smax, c, axis_in, np, j, flags, stages);
+  const int np_before = np;
+  np = QuadStagesFor<M, D, 1>::run(q, smax, c, axis_in, np, j, flags, stages, cmine);
   const bool done = np < 2;
   if (leader) {
     if (prm.done_out) prm.done_out[g] = done;
@@ -577,20 +714,81 @@ __global__ __launch_bounds__(kWave * WPB) void quad_kernel(const float* in0, int
     return;
   }
 #endif
-  // ---- in place: the row of every slot in use goes back to its own place in the image -- new coordinates if it
-  // survived, padding if it was removed; the dead rows that sit in the slots past the live ones are padding already and
-  // are rewritten as such (unconditional writes) ------------------------------------------------------------------------
-  unrolled_while<0, R>([&](auto sc) {
-    constexpr int s = decltype(sc)::value;
-    if (s >= smax) return false;
-    if (M % kQuad == 0 || kQuad * s + j < M) {
-      const bool removed = !(q[s * D] < INFINITY);
-      float* dst = mine + orig[s] * D;
+  if constexpr (!G::kBig) {
+    // ---- in place: the row of every slot in use goes back to its own place in the image -- new coordinates if it
+    // survived, padding if it was removed; the dead rows that sit in the slots past the live ones are padding already
+    // and are rewritten as such (unconditional writes) ----------------------------------------------------------------
+    unrolled_while<0, R>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if (s >= smax) return false;
+      if (M % kQuad == 0 || kQuad * s + j < M) {
+        const bool removed = !(q[s * D] < INFINITY);
+        float* dst = mine + orig[s] * D;
 #pragma unroll
-      for (int k = 0; k < D; ++k) dst[k] = removed ? pad : q[s * D + k];
+        for (int k = 0; k < D; ++k) dst[k] = removed ? pad : q[s * D + k];
+      }
+      return true;
+    });
+  } else {
+    // ---- large games: every slot in use returns its row (padding if it was removed) to its compact slot; the lane
+    // that OWNS row i (it scanned it, it knows its rank) picks it up there and rebuilds its rows of the image: a dead
+    // row is padding, as it was.  All reads of the compact image precede the first write of the slab image in the
+    // wave's program order, which is the order LDS serves them in. ----------------------------------------------------
+    unrolled_while<0, R>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if (s >= smax) return false;
+      if (kQuad * s + j < np_before) {
+        const bool removed = !(q[s * D] < INFINITY);
+        float* dst = cmine + (kQuad * s + j) * G::CW;
+        if constexpr (D == 4) {
+          *reinterpret_cast<vf4*>(dst) = vf4{removed ? pad : q[s * D], removed ? pad : q[s * D + 1],
+                                             removed ? pad : q[s * D + 2], removed ? pad : q[s * D + 3]};
+        } else {
+#pragma unroll
+          for (int k = 0; k < D; ++k) dst[k] = removed ? pad : q[s * D + k];
+        }
+      }
+      return true;
+    });
+    wave_lds_fence();
+    float fin[R * D];
+    {
+      int rank = below;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const bool live = (lmask >> r) & 1u;
+        const float* src = cmine + (live ? rank : 0) * G::CW;
+        if constexpr (D == 4) {
+          const vf4 v = *reinterpret_cast<const vf4*>(src);
+          fin[r * D] = live ? v.x : pad;
+          fin[r * D + 1] = live ? v.y : pad;
+          fin[r * D + 2] = live ? v.z : pad;
+          fin[r * D + 3] = live ? v.w : pad;
+        } else {
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            const float v = src[k];
+            fin[r * D + k] = live ? v : pad;
+          }
+        }
+        rank += live ? 1 : 0;
+      }
     }
-    return true;
-  });
+#pragma unroll
+    for (int e = 0; e < R * D; ++e) asm volatile("" : "+v"(fin[e]));  // every read is issued before the first write
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (M % kQuad == 0 || i0 + r < M) {
+        float* dst = mine + (i0 + r) * D;
+        if constexpr (D == 4) {
+          *reinterpret_cast<vf4*>(dst) = vf4{fin[r * D], fin[r * D + 1], fin[r * D + 2], fin[r * D + 3]};
+        } else {
+#pragma unroll
+          for (int k = 0; k < D; ++k) dst[k] = fin[r * D + k];
+        }
+      }
+    }
+  }
   wave_lds_fence();
   quad_slab_store<M, D>(image, (float*)prm.out + g0 * G::N, ngames, lane);
 }
@@ -600,7 +798,7 @@ template <int M, int D>
 constexpr int quad_waves_per_block() {
   // LDS per wave = image + compact image; keep a workgroup at or below 64 KiB of static LDS
   using G = QuadGeom<M, D>;
-  return ((G::kImage + G::kCompact) * 4 * 4 <= 64 * 1024) ? 4 : 1;
+  return (G::kRegion * 4 * 4 + 4 * kQuadGames * D * 4 <= 64 * 1024) ? 4 : 1;
 }
 
 template <int M, int D, int WPB, int HOT, int ACT>
@@ -686,10 +884,12 @@ inline bool quad_supported(const Params& prm, int dtype) {
   return false;
 }
 
-// where the four-lane kernel is the default choice (measured, scripts/probe_quad.py)
-inline bool quad_default(const Params& prm) {
-  if (prm.m * prm.d > 64) return false;  // (50,4): by HK_FLAG_FORCE_FOUR_LANES only, for now
-  return (int64_t)prm.batch * 2 <= (int64_t)3 * kWave * 1024;
+// where the four-lane kernel is the default choice (measured, scripts/probe_quad.py): the large games at any batch
+// ((50,4) x 262 144: 94 us against the team kernel's 113); the small ones while the one-lane kernel (64 games per
+// wave) would leave SIMDs short of a third wave -- beyond that its longer streams win ((20,3) x 524 288: 45.6 vs 47 us)
+inline bool quad_default(const Params& prm, int simds) {
+  if (prm.m * prm.d > 128) return true;
+  return (int64_t)prm.batch <= (int64_t)3 * kWave * simds;
 }
 
 #ifndef HK_SPEC_TU

@@ -33,7 +33,7 @@ def check(m, d, b, sem="jax", stages=STAGES, dense=False, act=0):
     if bad and "points" in bad:
         g = int((ref["points"] != got["points"]).any(dim=2).any(dim=1).nonzero()[0])
         print("game", g, "\nin\n", P[g].cpu().numpy(), "\nref\n", ref["points"][g].cpu().numpy(), "\ngot\n", got["points"][g].cpu().numpy(),
-              "cls", int(cls[g]), "axis", int(ax[g]))
+              "cls", cls[g].cpu().numpy(), "axis", ax[g].cpu().numpy())
     return not bad
 
 
@@ -53,6 +53,16 @@ def episode_time(m, d, b, force, dense=False, flags=0):
     return timeit(episode, iters=1, reps=50) / 20
 
 
+def fresh_step_time(m, d, b, force):
+    """bench.py's config3 protocol: independent launches from generate_pts states"""
+    P = ops.generate_points(b, m, d, 20, seed=42)
+    cls = torch.randint(0, 2 ** d - d - 1, (b,), dtype=torch.int32, device="cuda")
+    mask = ops.decode_host_class(cls, d, torch.float32)
+    ax = torch.randint(0, d, (b,), dtype=torch.int32, device="cuda")
+    out = torch.empty_like(P)
+    return timeit(lambda: ops.step(P, mask, ax, stages=STAGES, flags=force, out=out, want=("done", "reward")), iters=5, reps=20)
+
+
 ok = True
 for m, d in ((20, 3), (10, 3), (20, 4), (50, 4)):
     for b in (1, 17, 1000, 4099):
@@ -69,3 +79,5 @@ for m, d, b in ((20, 3, 65536), (20, 3, 32768), (20, 3, 131072), (20, 3, 524288)
         t2 = episode_time(m, d, b, A.HK_FLAG_FORCE_TWO_LANES if m * d <= 80 else 0, dense)
         t4 = episode_time(m, d, b, Q, dense)
         print(f"({m},{d}) b={b:7d} dense={dense}: default/two-lane {t2:7.2f} us   four-lane {t4:7.2f} us", flush=True)
+print(f"(50,4) b=262144 from generate_pts states: team {fresh_step_time(50, 4, 262144, 0):7.2f} us   four-lane {fresh_step_time(50, 4, 262144, Q):7.2f} us", flush=True)
+print(f"(20,3) b=65536 from generate_pts states: two-lane {fresh_step_time(20, 3, 65536, A.HK_FLAG_FORCE_TWO_LANES):7.2f} us   four-lane {fresh_step_time(20, 3, 65536, Q):7.2f} us", flush=True)
