@@ -259,10 +259,13 @@ __device__ __forceinline__ void d_newton(float (&q)[CH * D], int h) {
 }
 
 // one transition on slots [0, NB) of both lanes; returns the GAME's number of live rows
-template <int CH, int D, int NB>
+template <int CH, int D, int NB, bool BIN = false>
 __device__ __forceinline__ int d_stages(float (&q)[CH * D], const float (&c)[D], int axis, int np, int h,
-                                        unsigned flags, unsigned stages) {
-  if (stages & HK_STAGE_SHIFT) b_shift<CH, D, NB>(q, c, axis, np, flags);
+                                        unsigned flags, unsigned stages, uint32_t cmask = 0) {
+  if (stages & HK_STAGE_SHIFT) {
+    if constexpr (BIN) b_shift_mask<CH, D, NB>(q, cmask, axis, np, flags);
+    else b_shift<CH, D, NB>(q, c, axis, np, flags);
+  }
   if (stages & HK_STAGE_REPOSITION) d_reposition<CH, D, NB>(q, flags);
   if (stages & HK_STAGE_NEWTON) d_newton<CH, D, NB>(q, h);
   if (stages & HK_STAGE_RESCALE) d_rescale<CH, D, NB>(q, flags);
@@ -272,16 +275,16 @@ __device__ __forceinline__ int d_stages(float (&q)[CH * D], const float (&c)[D],
   return n + duo_other_i(n);
 }
 
-template <int CH, int D, int NB>
+template <int CH, int D, int NB, bool BIN = false>
 struct DuoStagesFor {
   static constexpr int kNext = (NB < 6) ? NB + 1 : NB + 2;
   static __device__ __forceinline__ int run(float (&q)[CH * D], int smax, const float (&c)[D], int axis, int np,
-                                            int h, unsigned flags, unsigned stages) {
+                                            int h, unsigned flags, unsigned stages, uint32_t cmask = 0) {
     if constexpr (NB >= CH) {
-      return d_stages<CH, D, CH>(q, c, axis, np, h, flags, stages);
+      return d_stages<CH, D, CH, BIN>(q, c, axis, np, h, flags, stages, cmask);
     } else {
-      if (smax <= NB) return d_stages<CH, D, NB>(q, c, axis, np, h, flags, stages);
-      return DuoStagesFor<CH, D, kNext>::run(q, smax, c, axis, np, h, flags, stages);
+      if (smax <= NB) return d_stages<CH, D, NB, BIN>(q, c, axis, np, h, flags, stages, cmask);
+      return DuoStagesFor<CH, D, kNext, BIN>::run(q, smax, c, axis, np, h, flags, stages, cmask);
     }
   }
 };
@@ -455,15 +458,15 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
       __syncthreads();
       duo_store_slab<M, D, 2>(lds, (float*)prm.obs_out + (int64_t)t * prm.batch * G::N, (int64_t)G::N, g0, ngames, lane);
     }
+    uint32_t mask = 0;
     if (kRoll) {
-      uint32_t mask, ra, rb;
+      uint32_t ra, rb;
       duo_policy_words(gg, step0 + (uint32_t)t, seed, dcache, h, ra, rb);
       policy_from_words<D>(ra, rb, host_policy, agent_policy, cls, axis, mask, 0);
-#pragma unroll
-      for (int k = 0; k < D; ++k) c[k] = (float)((mask >> k) & 1u);
     }
     const bool prev_done = np < 2;
-    np = DuoStagesFor<CH, D, 1>::run(q, smax, c, axis, np, h, flags, stages);
+    // (rollouts: the subset is the policy's 0/1 mask -- the shift as selects, see b_shift_mask)
+    np = DuoStagesFor<CH, D, 1, kRoll>::run(q, smax, c, axis, np, h, flags, stages, mask);
     if (!active) np = 2;
     const bool done = np < 2;
     if (done && length < 0) length = t + 1;
@@ -480,9 +483,24 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
       if (prm.r_done_out) prm.r_done_out[at] = done;
       if (prm.r_reward_out) prm.r_reward_out[at] = prm.reward_sign * (float)(done && !prev_done);
     }
-    if (count_slot) {
-      const unsigned long long bd = __ballot(leader && done);
-      if (lane == 0) count_add(count_slot + (size_t)(t + 1) * count_stride, (uint32_t)__popcll(bd));
+    const unsigned long long bd = __ballot(leader && done);
+    if (count_slot && lane == 0) count_add(count_slot + (size_t)(t + 1) * count_stride, (uint32_t)__popcll(bd));
+    // Fixed point: a game that is down to ONE point sitting at the origin (or to none) does not change any more --
+    // whatever the subset and the axis: the shift adds zeros, reposition / rescale find nothing to move, the Newton
+    // stage has nothing to compare.  Once every game of the wave is there (a game reaches it one step after it ends
+    // when reposition is on; the mean game lasts 5 steps, the longest of 32 about 13), the rest of the episode is
+    // the finished-game counts, added in closed form.
+    if (MODE == kModeRollout && smax == 1 && bd == __ballot(leader) && t + 1 < nsteps) {
+      // (one slot per lane left: a lane holds the game's point, a hole, or nothing)
+      bool still = true;
+#pragma unroll
+      for (int k = 0; k < D; ++k) still &= (q[k] == 0.0f);
+      still |= !(q[0] < INFINITY);
+      if (!__any(active && !still)) {
+        if (count_slot && lane == 0)
+          for (int tt = t + 1; tt < nsteps; ++tt) count_add(count_slot + (size_t)(tt + 1) * count_stride, (uint32_t)__popcll(bd));
+        break;
+      }
     }
     // re-deal the rows when the widest game of the wave fits fewer slots per lane
     if (t + 1 < nsteps && !__any(active && ((np + 1) >> 1) >= smax)) {

@@ -504,6 +504,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
                  "+s"(agent_policy));
   for (int t = 0; t < nsteps; ++t) {
     int axis = -1, cls = 0;
+    uint32_t mask = 0;  // rollouts: the policy's subset as a 0/1 mask (the shift as selects, b_shift_mask)
     if (kRoll) {
       if (want_obs) {  // state before the step: rebuild the image, store it coalesced
         __syncthreads();
@@ -513,12 +514,9 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
         fast_store_slab<M, D>(lds, (float*)prm.obs_out + (int64_t)t * prm.batch * G::N, (int64_t)G::N,
                               g0, ngames, lane);
       }
-      uint32_t mask;
       int zc = 0;
       if (!HOT && host_policy == HK_HOST_ZEILLINGER) zc = c_zeillinger<G::C, D>(q, nmax);
       fast_policy<D>(seed, host_policy, agent_policy, gg, step0 + (uint32_t)t, pcache, cls, axis, mask, zc);
-#pragma unroll
-      for (int k = 0; k < D; ++k) c[k] = (float)((mask >> k) & 1u);
     } else if (kStep) {
       axis = axis_in;  // c[] and the axis were fetched at kernel entry
     }
@@ -528,7 +526,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
       // list semantics: right after the Newton stage (before a rescale could round two keys together) the
       // survivors are sorted descending-lexicographically and packed to the front -- physically: rows to
       // their rank in the image, slots 0..n-1 become the game's live slots, registers re-gathered in that order
-      np = run_stages<G::C, D>(q, nmax, c, axis, np, flags, stages & ~(unsigned)HK_STAGE_RESCALE);
+      np = run_stages<G::C, D, kRoll>(q, nmax, c, axis, np, flags, stages & ~(unsigned)HK_STAGE_RESCALE, mask);
       int rank[G::C];
       feature_ranks<G::C, D, kKeyFirst>(q, nmax, rank);
       __syncthreads();
@@ -540,7 +538,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
       gather_rows<M, G::C, D>(q, mine, gmask, nprev);
       if (stages & HK_STAGE_RESCALE) np = run_stages<G::C, D>(q, nmax, c, axis, np, flags, HK_STAGE_RESCALE);
     } else {
-      np = run_stages<G::C, D>(q, nmax, c, axis, np, flags, stages);  // branch-free body for >= nmax rows
+      np = run_stages<G::C, D, kRoll>(q, nmax, c, axis, np, flags, stages, mask);  // branch-free body for >= nmax rows
     }
     if (!active) np = 2;
     const bool done = np < 2;
@@ -553,9 +551,20 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
         if (prm.r_done_out) prm.r_done_out[at] = done;
         if (prm.r_reward_out) prm.r_reward_out[at] = prm.reward_sign * (float)(done && !prev_done);
       }
-      if (count_slot) {
-        const unsigned long long bd = __ballot(active && done);
-        if (lane == 0) count_add(count_slot + (size_t)(t + 1) * count_stride, (uint32_t)__popcll(bd));
+      const unsigned long long bd = __ballot(active && done);
+      if (count_slot && lane == 0) count_add(count_slot + (size_t)(t + 1) * count_stride, (uint32_t)__popcll(bd));
+      // Fixed point (see hk_duo_kernel.h): once every game of the wave is down to one point at the origin (or none)
+      // nothing changes any more; the rest of the episode is the finished-game counts, in closed form.
+      if (MODE == kModeRollout && nmax == 1 && bd == __ballot(active) && t + 1 < nsteps) {
+        bool still = true;
+#pragma unroll
+        for (int k = 0; k < D; ++k) still &= (q[k] == 0.0f);
+        still |= !(q[0] < INFINITY);
+        if (!__any(active && !still)) {
+          if (count_slot && lane == 0)
+            for (int tt = t + 1; tt < nsteps; ++tt) count_add(count_slot + (size_t)(tt + 1) * count_stride, (uint32_t)__popcll(bd));
+          break;
+        }
       }
       // re-gather when the widest game of the wave got narrower (removed rows are holes until then)
       // (one ballot per step; the cross-lane maximum only when some game still fills all nmax rows)

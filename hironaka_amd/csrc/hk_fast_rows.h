@@ -147,16 +147,20 @@ __device__ __forceinline__ void c_reposition(float (&q)[C * D], int nmax, unsign
   });
 }
 
+// t = max_k(a - b), u = min_k(a - b).  The differences are results of a subtraction (canonical), so plain fmaxf /
+// fminf chains become v_max3_f32 / v_min3_f32 (one instruction per three values) without the canonicalising
+// v_max x, x that values of unknown origin get; hk_fmax / hk_fmin (v_med3) stay for those.
 template <int D>
 __device__ __forceinline__ void diff_extrema(const float* a, const float* b, float& t, float& u) {
-  const float d0 = a[0] - b[0];
-  t = d0;
-  u = d0;
+  float dk[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) dk[k] = a[k] - b[k];
+  t = dk[0];
+  u = dk[0];
 #pragma unroll
   for (int k = 1; k < D; ++k) {
-    const float dk = a[k] - b[k];
-    t = hk_fmax(t, dk);
-    u = hk_fmin(u, dk);
+    t = __builtin_fmaxf(t, dk[k]);
+    u = __builtin_fminf(u, dk[k]);
   }
 }
 
@@ -248,6 +252,31 @@ __device__ __forceinline__ void b_shift(float (&q)[C * D], const float (&c)[D], 
   }
 }
 
+// The same shift when the subset is known to be a 0/1 mask (the in-kernel policies: bits of `cmask`): the sum of the
+// chosen coordinates as selects instead of products.  Bit-identical on the rows this code sees (finite, >= +0:
+// x*1 = x, x*0 = +0 and 0 + a = a), two instructions per row shorter, and a hole (all +inf) stays all +inf by itself
+// -- every subset has two coordinates or more, inf + 0 = inf and there is no inf*0 -- so no per-row `live` test.
+template <int C, int D, int NB>
+__device__ __forceinline__ void b_shift_mask(float (&q)[C * D], uint32_t cmask, int axis, int np, unsigned flags) {
+  bool apply = true;
+  if (flags & HK_FLAG_AXIS_NOOP_IF_INVALID) apply = axis >= 0 && ((cmask >> axis) & 1u);
+  if ((flags & HK_FLAG_IGNORE_ENDED) && np < 2) apply = false;
+  bool isax[D], in[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    isax[k] = apply && (k == axis);
+    in[k] = (cmask >> k) & 1u;
+  }
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    float s = in[0] ? q[r * D] : 0.0f;
+#pragma unroll
+    for (int k = 1; k < D; ++k) s = s + (in[k] ? q[r * D + k] : 0.0f);  // order 0..D-1
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[r * D + k] = isax[k] ? s : q[r * D + k];
+  }
+}
+
 template <int C, int D, int NB>
 __device__ __forceinline__ void b_reposition(float (&q)[C * D], unsigned flags) {
   const bool jax_sem = (flags & HK_SEM_MASK) == HK_SEM_JAX;
@@ -314,11 +343,14 @@ __device__ __forceinline__ void b_rescale(float (&q)[C * D], unsigned flags) {
   }
 }
 
-// one transition on rows [0, NB); returns the number of live rows
-template <int C, int D, int NB>
+// one transition on rows [0, NB); returns the number of live rows.  BIN: the subset is the 0/1 mask `cmask`
+template <int C, int D, int NB, bool BIN = false>
 __device__ __forceinline__ int b_stages(float (&q)[C * D], const float (&c)[D], int axis, int np, unsigned flags,
-                                        unsigned stages) {
-  if (stages & HK_STAGE_SHIFT) b_shift<C, D, NB>(q, c, axis, np, flags);
+                                        unsigned stages, uint32_t cmask = 0) {
+  if (stages & HK_STAGE_SHIFT) {
+    if constexpr (BIN) b_shift_mask<C, D, NB>(q, cmask, axis, np, flags);
+    else b_shift<C, D, NB>(q, c, axis, np, flags);
+  }
   if (stages & HK_STAGE_REPOSITION) b_reposition<C, D, NB>(q, flags);
   if (stages & HK_STAGE_NEWTON) b_newton<C, D, NB>(q);
   if (stages & HK_STAGE_RESCALE) b_rescale<C, D, NB>(q, flags);
@@ -329,24 +361,24 @@ __device__ __forceinline__ int b_stages(float (&q)[C * D], const float (&c)[D], 
 }
 
 // the smallest body that covers nmax
-template <int C, int D, int NB>
+template <int C, int D, int NB, bool BIN = false>
 struct StagesFor {
   static constexpr int kNext = (NB < 8) ? NB + 1 : NB + 2;
   static __device__ __forceinline__ int run(float (&q)[C * D], int nmax, const float (&c)[D], int axis, int np,
-                                            unsigned flags, unsigned stages) {
+                                            unsigned flags, unsigned stages, uint32_t cmask = 0) {
     if constexpr (NB >= C) {
-      return b_stages<C, D, C>(q, c, axis, np, flags, stages);
+      return b_stages<C, D, C, BIN>(q, c, axis, np, flags, stages, cmask);
     } else {
-      if (nmax <= NB) return b_stages<C, D, NB>(q, c, axis, np, flags, stages);
-      return StagesFor<C, D, kNext>::run(q, nmax, c, axis, np, flags, stages);
+      if (nmax <= NB) return b_stages<C, D, NB, BIN>(q, c, axis, np, flags, stages, cmask);
+      return StagesFor<C, D, kNext, BIN>::run(q, nmax, c, axis, np, flags, stages, cmask);
     }
   }
 };
 
-template <int C, int D>
+template <int C, int D, bool BIN = false>
 __device__ __forceinline__ int run_stages(float (&q)[C * D], int nmax, const float (&c)[D], int axis, int np,
-                                          unsigned flags, unsigned stages) {
-  return StagesFor<C, D, 1>::run(q, nmax, c, axis, np, flags, stages);
+                                          unsigned flags, unsigned stages, uint32_t cmask = 0) {
+  return StagesFor<C, D, 1, BIN>::run(q, nmax, c, axis, np, flags, stages, cmask);
 }
 
 // ---- observation features (jax/util.py:186-197): rows in descending order, LAST coordinate primary ------
