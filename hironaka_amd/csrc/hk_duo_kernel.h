@@ -289,6 +289,44 @@ struct DuoStagesFor {
   }
 };
 
+// ---- list semantics for plain rollouts: the pair's rows ranked in descending lexicographic order (coordinate 0
+// first; rows are distinct after a Newton stage) and written to their rank, once, at the end of the launch -------------
+template <int CH, int D>
+__device__ __forceinline__ void duo_ranks_first(const float (&q)[CH * D], int smax, int (&rank)[CH]) {
+#pragma unroll
+  for (int s = 0; s < CH; ++s) rank[s] = 0;
+  unrolled_while<0, CH>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    if (b >= smax) return false;
+    float o[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) o[k] = duo_other(q[b * D + k]);
+    const bool live_o = o[0] < INFINITY, live_b = q[b * D] < INFINITY;
+    unrolled_while<0, CH>([&](auto ac) {
+      constexpr int a = decltype(ac)::value;
+      if (a >= smax) return false;
+      rank[a] += (live_o && key_gt<D, kKeyFirst>(o, &q[a * D])) ? 1 : 0;                      // the partner's row b
+      if (a != b) rank[a] += (live_b && key_gt<D, kKeyFirst>(&q[b * D], &q[a * D])) ? 1 : 0;  // my own row b
+      return true;
+    });
+    return true;
+  });
+}
+
+template <int CH, int D>
+__device__ __forceinline__ void duo_scatter_ranked(const float (&q)[CH * D], float* mine, const int (&rank)[CH], int smax) {
+  unrolled_while<0, CH>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (s >= smax) return false;
+    if (q[s * D] < INFINITY) {
+      float* row = mine + rank[s] * D;
+#pragma unroll
+      for (int k = 0; k < D; ++k) row[k] = q[s * D + k];
+    }
+    return true;
+  });
+}
+
 // The policy stream of a pair: Philox block b (steps 2b, 2b + 1) is computed by the lane with (b & 1) == h only
 // -- one Philox per lane per FOUR steps -- and its two words reach the partner through DPP.
 struct DuoPolicyCache {
@@ -340,6 +378,11 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   const unsigned stages = HOT ? (unsigned)(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON) : prm.stages;
   const float fill = ((flags & HK_SEM_MASK) == HK_SEM_JAX) ? -1.0f : pad;
   const int nsteps = kRoll ? prm.steps : 1;
+  // plain rollouts under list semantics sort once, at the end (see hk_fast_kernel.h)
+  constexpr bool kEndSort = MODE == kModeRollout && HOT == kHotNone;
+  const bool end_sort = kEndSort && nsteps > 0 && (stages & HK_STAGE_NEWTON) &&
+                        ((flags & HK_SEM_MASK) == HK_SEM_LIST || (flags & HK_FLAG_COMPACT_SORTED));
+  bool rescale_pending = false;
   PolicyCache pcache;      // slow path (one lane per game computes)
   DuoPolicyCache dcache;
   float c[D];
@@ -466,7 +509,9 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
     }
     const bool prev_done = np < 2;
     // (rollouts: the subset is the policy's 0/1 mask -- the shift as selects, see b_shift_mask)
-    np = DuoStagesFor<CH, D, 1, kRoll>::run(q, smax, c, axis, np, h, flags, stages, mask);
+    const unsigned st = (end_sort && t + 1 == nsteps) ? (stages & ~(unsigned)HK_STAGE_RESCALE) : stages;
+    rescale_pending = end_sort && t + 1 == nsteps && (stages & HK_STAGE_RESCALE);
+    np = DuoStagesFor<CH, D, 1, kRoll>::run(q, smax, c, axis, np, h, flags, st, mask);
     if (!active) np = 2;
     const bool done = np < 2;
     if (done && length < 0) length = t + 1;
@@ -519,7 +564,14 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   __syncthreads();
   if (h == 0) fill_image<M, D>(mine, pad);
   __syncthreads();
-  duo_scatter<M, CH, D>(q, mine, gmask, smax, h);
+  if (kEndSort && end_sort) {
+    int rank[CH];
+    duo_ranks_first<CH, D>(q, smax, rank);
+    if (rescale_pending) d_rescale<CH, D, CH>(q, flags);
+    duo_scatter_ranked<CH, D>(q, mine, rank, smax);
+  } else {
+    duo_scatter<M, CH, D>(q, mine, gmask, smax, h);
+  }
   __syncthreads();
   duo_store_slab<M, D>(lds, (float*)prm.out, prm.out_stride, g0, ngames, lane);
 }
@@ -546,8 +598,11 @@ inline bool duo_wanted(const Params& prm) {
   if (prm.mode == kModeStep && (prm.class_out || (prm.stages & kStageFeatureSorts))) return false;
   if (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER) return false;
   if ((prm.stages & HK_STAGE_NEWTON) &&
-      ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)))
-    return false;
+      ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED))) {
+    // sorted + compacted output: plain rollouts only (they sort once, at the end)
+    const bool records = prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out;
+    if (prm.mode != kModeRollout || records) return false;
+  }
   if (prm.flags & HK_FLAG_FORCE_TWO_LANES) return true;
   // measured (scripts/probe_duo.py): ahead while the one-lane kernel (64 games per wave) leaves SIMDs short of
   // a second wave -- up to 1.5 waves per SIMD, 98 304 games on the 1024 SIMDs of an MI355X -- and at any size

@@ -362,6 +362,13 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   constexpr bool kSortedCapable = MODE == kModeStepAux || MODE == kModeRolloutRec;
   const bool sorted_out = kSortedCapable && (stages & HK_STAGE_NEWTON) &&
                           ((flags & HK_SEM_MASK) == HK_SEM_LIST || (flags & HK_FLAG_COMPACT_SORTED));
+  // A PLAIN rollout (no per-step records) under list semantics sorts once, at the end: between two Newton stages
+  // the order of the rows changes nothing (the stage removes duplicates and dominated rows whatever their order;
+  // the policies and counts do not look at it), so only the state that leaves the kernel has to be sorted +
+  // compacted -- ranked right after the last Newton stage, before a rescale could round two keys together.
+  constexpr bool kEndSort = MODE == kModeRollout && HOT == kHotNone;
+  const bool end_sort = kEndSort && nsteps > 0 && (stages & HK_STAGE_NEWTON) &&
+                        ((flags & HK_SEM_MASK) == HK_SEM_LIST || (flags & HK_FLAG_COMPACT_SORTED));
   PolicyCache pcache;
 
   // step mode: the action loads join the slab's requests in flight
@@ -502,6 +509,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   else
     asm volatile("" : "+s"(count_slot), "+s"(count_stride), "+s"(step0), "+s"(seed), "+s"(host_policy),
                  "+s"(agent_policy));
+  bool rescale_pending = false;
   for (int t = 0; t < nsteps; ++t) {
     int axis = -1, cls = 0;
     uint32_t mask = 0;  // rollouts: the policy's subset as a 0/1 mask (the shift as selects, b_shift_mask)
@@ -538,7 +546,10 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
       gather_rows<M, G::C, D>(q, mine, gmask, nprev);
       if (stages & HK_STAGE_RESCALE) np = run_stages<G::C, D>(q, nmax, c, axis, np, flags, HK_STAGE_RESCALE);
     } else {
-      np = run_stages<G::C, D, kRoll>(q, nmax, c, axis, np, flags, stages, mask);  // branch-free body for >= nmax rows
+      // (end_sort: the last step's rescale waits until the rows are ranked, after the loop)
+      const unsigned st = (end_sort && t + 1 == nsteps) ? (stages & ~(unsigned)HK_STAGE_RESCALE) : stages;
+      np = run_stages<G::C, D, kRoll>(q, nmax, c, axis, np, flags, st, mask);  // branch-free body for >= nmax rows
+      rescale_pending = end_sort && t + 1 == nsteps && (stages & HK_STAGE_RESCALE);
     }
     if (!active) np = 2;
     const bool done = np < 2;
@@ -590,6 +601,11 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   if (MODE == kModeStepAux && (stages & kStageFeatureSorts)) {
     int rank[G::C];
     feature_ranks<G::C, D, kKeyLast>(q, nmax, rank, (stages & kStageFeatureSort0) != 0);
+    scatter_ranked<G::C, D>(q, mine, rank, nmax);
+  } else if (kEndSort && end_sort) {
+    int rank[G::C];
+    feature_ranks<G::C, D, kKeyFirst>(q, nmax, rank);
+    if (rescale_pending) c_rescale<G::C, D>(q, nmax, flags);
     scatter_ranked<G::C, D>(q, mine, rank, nmax);
   } else {
     scatter_rows<M, G::C, D>(q, mine, gmask, nmax);
@@ -655,7 +671,7 @@ int launch_fast_t(Params prm, hipStream_t stream) {
   else if (prm.mode == kModeStep)
     hipLaunchKernelGGL((fast_kernel<M, D, kModeStep>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
                        prm.in_stride, prm.batch, prm.games_per_block, prm);
-  else if (prm.mode == kModeRollout && (sorted_out || prm.obs_out || prm.r_host_class_out || prm.r_axis_out ||
+  else if (prm.mode == kModeRollout && (prm.obs_out || prm.r_host_class_out || prm.r_axis_out ||
                                         prm.r_done_out || prm.r_reward_out))
     hipLaunchKernelGGL((fast_kernel<M, D, kModeRolloutRec>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
                        prm.in_stride, prm.batch, prm.games_per_block, prm);

@@ -356,15 +356,46 @@ __device__ __forceinline__ void qd_newton_lds(float (&q)[R * D], float* cmine, i
   wave_lds_fence();  // the compact image is written again after the stages
 }
 
-// one transition on slots [0, NB) of the four lanes; returns the GAME's number of live rows
+// list semantics (_list_ops.py:25-41): position of each of the lane's rows among the game's live rows in descending
+// lexicographic order, coordinate 0 first (rows are distinct after the Newton stage): the rows of the other three
+// lanes arrive through DPP, every lane counts for its own rows
+template <int R, int D, int NB>
+__device__ __forceinline__ void qd_ranks_first(const float (&q)[R * D], int (&rank)[R]) {
+#pragma unroll
+  for (int s = 0; s < R; ++s) rank[s] = 0;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    float p1[D], p2[D], p3[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      p1[k] = qperm<kQuadUp1>(q[b * D + k]);
+      p2[k] = qperm<kQuadUp2>(q[b * D + k]);
+      p3[k] = qperm<kQuadUp3>(q[b * D + k]);
+    }
+    const bool l0 = q[b * D] < INFINITY, l1 = p1[0] < INFINITY, l2 = p2[0] < INFINITY, l3 = p3[0] < INFINITY;
+#pragma unroll
+    for (int a = 0; a < NB; ++a) {
+      if (a != b) rank[a] += (l0 && key_gt<D, kKeyFirst>(&q[b * D], &q[a * D])) ? 1 : 0;
+      rank[a] += (l1 && key_gt<D, kKeyFirst>(p1, &q[a * D])) ? 1 : 0;
+      rank[a] += (l2 && key_gt<D, kKeyFirst>(p2, &q[a * D])) ? 1 : 0;
+      rank[a] += (l3 && key_gt<D, kKeyFirst>(p3, &q[a * D])) ? 1 : 0;
+    }
+  }
+}
+
+// one transition on slots [0, NB) of the four lanes; returns the GAME's number of live rows.  `sorted` (list
+// semantics): the survivors are ranked right after the Newton stage, before a rescale could round two keys together.
 template <int M, int CW, int R, int D, int NB>
 __device__ __forceinline__ int qd_stages(float (&q)[R * D], const float (&c)[D], int axis, int np, int j,
-                                         unsigned flags, unsigned stages, float* cmine, int slots_end) {
+                                         unsigned flags, unsigned stages, float* cmine, int slots_end, bool sorted,
+                                         int (&rank)[R]) {
   if (stages & HK_STAGE_SHIFT) b_shift<R, D, NB>(q, c, axis, np, flags);
   if (stages & HK_STAGE_REPOSITION) qd_reposition<R, D, NB>(q, flags);
   if (stages & HK_STAGE_NEWTON) {
     if constexpr (NB > kQuadDppSlots) qd_newton_lds<M, CW, R, D, NB>(q, cmine, j, slots_end);
     else qd_newton<R, D, NB>(q, j);
+    if constexpr (NB <= kQuadDppSlots)
+      if (sorted) qd_ranks_first<R, D, NB>(q, rank);
   }
   if (stages & HK_STAGE_RESCALE) qd_rescale<R, D, NB>(q, flags);
   int n = 0;
@@ -377,13 +408,15 @@ template <int M, int D, int NB>
 struct QuadStagesFor {
   using G = QuadGeom<M, D>;
   static __device__ __forceinline__ int run(float (&q)[G::R * D], int smax, const float (&c)[D], int axis, int np,
-                                            int j, unsigned flags, unsigned stages, float* cmine) {
+                                            int j, unsigned flags, unsigned stages, float* cmine, bool sorted,
+                                            int (&rank)[G::R]) {
     const int slots_end = kQuad * smax < M ? kQuad * smax : M;
     if constexpr (NB >= G::R) {
-      return qd_stages<M, G::CW, G::R, D, G::R>(q, c, axis, np, j, flags, stages, cmine, slots_end);
+      return qd_stages<M, G::CW, G::R, D, G::R>(q, c, axis, np, j, flags, stages, cmine, slots_end, sorted, rank);
     } else {
-      if (smax <= NB) return qd_stages<M, G::CW, G::R, D, NB>(q, c, axis, np, j, flags, stages, cmine, slots_end);
-      return QuadStagesFor<M, D, G::next_bucket(NB)>::run(q, smax, c, axis, np, j, flags, stages, cmine);
+      if (smax <= NB)
+        return qd_stages<M, G::CW, G::R, D, NB>(q, c, axis, np, j, flags, stages, cmine, slots_end, sorted, rank);
+      return QuadStagesFor<M, D, G::next_bucket(NB)>::run(q, smax, c, axis, np, j, flags, stages, cmine, sorted, rank);
     }
   }
 };
@@ -695,7 +728,11 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kBig ? 2 : 4)) void q
   // ---- the transition -------------------------------------------------------------------------------------------------
   const bool prev_done = np < 2;
   const int np_before = np;
-  np = QuadStagesFor<M, D, 1>::run(q, smax, c, axis_in, np, j, flags, stages, cmine);
+  // list semantics / COMPACT_SORTED (small games, run-time configured kernels only): sorted + compacted output
+  const bool sorted = !G::kBig && HOT == kHotNone && (stages & HK_STAGE_NEWTON) &&
+                      ((flags & HK_SEM_MASK) == HK_SEM_LIST || (flags & HK_FLAG_COMPACT_SORTED));
+  int rank[R];
+  np = QuadStagesFor<M, D, 1>::run(q, smax, c, axis_in, np, j, flags, stages, cmine, sorted, rank);
   const bool done = np < 2;
   if (leader) {
     if (prm.done_out) prm.done_out[g] = done;
@@ -714,7 +751,32 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kBig ? 2 : 4)) void q
     return;
   }
 #endif
-  if constexpr (!G::kBig) {
+  if (!G::kBig && sorted) {
+    // ---- list semantics: padding everywhere (the quads fill the wave's image in 16-B pieces), then every survivor at
+    // its rank -----------------------------------------------------------------------------------------------------
+    if constexpr (!G::kBig) {
+#pragma unroll
+      for (int it = 0; it < G::QL; ++it) {
+        const int qq = lane + it * kWave;
+        if (qq < kQuadGames * G::Q) {
+          if constexpr (G::W == 4) *reinterpret_cast<vf4*>(image + qq * 4) = vf4{pad, pad, pad, pad};
+          else if constexpr (G::W == 2) *reinterpret_cast<vf2*>(image + qq * 2) = vf2{pad, pad};
+          else image[qq] = pad;
+        }
+      }
+      wave_lds_fence();
+      unrolled_while<0, R>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if (s >= smax) return false;
+        if (q[s * D] < INFINITY) {
+          float* dst = mine + rank[s] * D;
+#pragma unroll
+          for (int k = 0; k < D; ++k) dst[k] = q[s * D + k];
+        }
+        return true;
+      });
+    }
+  } else if constexpr (!G::kBig) {
     // ---- in place: the row of every slot in use goes back to its own place in the image -- new coordinates if it
     // survived, padding if it was removed; the dead rows that sit in the slots past the live ones are padding already
     // and are rewritten as such (unconditional writes) ----------------------------------------------------------------
@@ -875,9 +937,9 @@ inline bool quad_supported(const Params& prm, int dtype) {
   if (prm.coords_kind == HK_COORDS_IN_RECORD) return false;
   if (prm.flags & (HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_TEAM | HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES))
     return false;
-  if ((prm.stages & HK_STAGE_NEWTON) &&
-      ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)))
-    return false;
+  const bool sorted = (prm.stages & HK_STAGE_NEWTON) &&
+                      ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED));
+  if (sorted && prm.m * prm.d > 128) return false;  // (the large games' sorted output stays with the team kernel)
 #define HK_X(M_, D_) if (prm.m == M_ && prm.d == D_) return quad_ok_t<M_, D_>(prm);
   HK_QUAD_SPECS(HK_X)
 #undef HK_X
