@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof_<tag>/ (scripts/profile_round.sh) into profiles/<tag>_*:
-kernel stats CSV, per-kernel durations split by launch shape, a PMC table per kernel variant, and the
-measured HBM traffic per launch that bench.py reports as roofline.traffic."""
+"""Condense gpurun_out/prof_<tag>/ (scripts/profile_round.sh) into <outdir>/<tag>_* (default outdir: profiles/):
+rocprofv3's kernel stats, per-kernel durations split by launch shape, a PMC table per (kernel, launch shape), and
+the per-launch constants bench.py reports (HBM bytes, VALU instructions, share of HIP kernels in the search).
+
+    python scripts/summarise_profile.py r02 [outdir]
+"""
 import collections
 import csv
 import glob
@@ -14,40 +17,53 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-dst = os.path.join(ROOT, "profiles")
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-HEADLINE_GRID = "131072"  # 2048 waves x 64 lanes = 65 536 games, two lanes each (BASELINE configs[1])
-HEADLINE_KERNEL = re.compile(r"duo_kernel<20, 3, 1, 1>")  # hk::duo_kernel<20,3,rollout,kHotJax>
-STEP_KERNEL = re.compile(r"duo_kernel<20, 3, 0, 1>")      # hk::duo_kernel<20,3,step,jax> (hk_step as bench.py calls it)
 
-stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
-if stats:
-    shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
-bj = os.path.join(src, "bench_trace.json")
-if os.path.exists(bj):
-    shutil.copy(bj, os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
+# the launches bench.py's headline numbers come from (kernel name pattern, grid size in threads)
+ROLLOUT = (re.compile(r"duo_kernel<20, 3, 1, 1>"), "131072")   # fused rollout, 65 536 games, two lanes per game
+STEP = (re.compile(r"quad_kernel<20, 3, 1, \d, 1>"), "262144")  # hk_step (JAX-trainer configuration, f32 mask + i32 axis)
+STEP3 = (re.compile(r"quad_kernel<50, 4, 1, \d, 1>"), "1048576")  # hk_step at (50,4) x 262 144
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")[:80]
 
 
 def split_rollout(durs):
     """dispatches of the rollout kernel at one grid size: fused 20-step episodes vs single steps"""
-    v = np.asarray(durs)
+    v = np.asarray(durs, dtype=float)
     cut = 0.6 * v.max()
     return v > cut, v <= cut
 
 
-# per-dispatch durations from the kernel trace, per (kernel, grid size)
-trace = glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True)
+def first(pattern):
+    hits = glob.glob(os.path.join(src, pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+stats = first("trace/**/*kernel_stats.csv")
+if stats:
+    shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+bj = os.path.join(src, "bench_trace.json")
+if os.path.exists(bj):
+    shutil.copy(bj, os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
+
+# ---- per-dispatch durations from the kernel trace, per (kernel, grid size) --------------------------------------
 lines = []
+trace = first("trace/**/*kernel_trace.csv")
 if trace:
     by = collections.defaultdict(list)
-    for r in csv.DictReader(open(trace[0])):
+    for r in csv.DictReader(open(trace)):
         by[(r["Kernel_Name"], r["Grid_Size_X"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     lines.append("kernel,grid_threads,calls,mean_us,p50_us,p95_us")
     for (k, grid), v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
         v = np.array(v)
-        if ("fast_kernel<" in k or "duo_kernel<" in k) and k.split("<")[1].split(",")[2].strip(" >") == "1":  # rollout mode
+        is_rollout = re.search(r"(fast|duo)_kernel<\d+, \d+, 1, \d>", k) is not None
+        parts = (("T=20 episodes", None), ("T=1 steps", None)) if is_rollout else (("", None),)
+        if is_rollout:
             big, small = split_rollout(v)
             parts = (("T=20 episodes", big), ("T=1 steps", small))
         else:
@@ -55,60 +71,95 @@ if trace:
         for name, sel in parts:
             if sel.any():
                 w = v[sel]
-                label = f"{k} [{name}]" if name else k
+                label = f"{short(k)} [{name}]" if name else short(k)
                 lines.append(f"\"{label}\",{grid},{len(w)},{w.mean()/1e3:.3f},{np.median(w)/1e3:.3f},"
                              f"{np.percentile(w, 95)/1e3:.3f}")
     open(os.path.join(dst, f"{tag}_kernel_durations.csv"), "w").write("\n".join(lines) + "\n")
 
-pmc_rows = ["# rocprofv3 --pmc passes (own runs, --kernel-trace only) of bench.py --steps 2000; means per dispatch at",
-            "# the headline launch shape (2048 waves x 32 games): rollout = hk::duo_kernel<20,3,rollout,jax> with 20 steps",
-            "# (T20) or one step (T1) per launch, step = hk::duo_kernel<20,3,step> (hk_step).  FETCH_SIZE / WRITE_SIZE in",
-            "# KiB; on gfx950 FETCH_SIZE tallies 64 B per 128-B request: read bytes = 2 x FETCH_SIZE KiB",
-            "# (MI355X_MICROARCH.md, HBM).",
-            "counter,rollout_T20,rollout_T20_per_wave,rollout_T1,rollout_T1_per_wave,step,step_per_wave"]
-traffic = {}
+# ---- PMC passes: means per dispatch and per wave for every launch shape with enough samples ------------------------
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(d):
         continue
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if not f:
         continue
-    roll = collections.defaultdict(dict)
-    step = collections.defaultdict(dict)
+    per_dispatch = collections.defaultdict(dict)
     for r in csv.DictReader(open(f[0])):
-        if r["Grid_Size"] != HEADLINE_GRID:
-            continue
-        if HEADLINE_KERNEL.search(r["Kernel_Name"]):  # the JAX-configuration rollout kernel only
-            e = roll[r["Dispatch_Id"]]
-        elif STEP_KERNEL.search(r["Kernel_Name"]):
-            e = step[r["Dispatch_Id"]]
-        else:
-            continue
+        e = per_dispatch[r["Dispatch_Id"]]
+        e["key"] = (r["Kernel_Name"], r["Grid_Size"])
         e[r["Counter_Name"]] = float(r["Counter_Value"])
         e["duration_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    if not roll:
+    groups = collections.defaultdict(list)
+    for e in per_dispatch.values():
+        groups[e["key"]].append(e)
+    for (k, grid), rows in groups.items():
+        if ROLLOUT[0].search(k):
+            big, small = split_rollout([e["duration_ns"] for e in rows])
+            sets = ((f"{short(k)} [T=20]", [e for e, s in zip(rows, big) if s]),
+                    (f"{short(k)} [T=1]", [e for e, s in zip(rows, small) if s]))
+        else:
+            sets = ((short(k), rows),)
+        for label, sub in sets:
+            for e in sub:
+                for c, v in e.items():
+                    if c != "key":
+                        agg[(label, grid)][c].append(v)
+
+pmc_rows = ["# rocprofv3 --pmc passes (own runs, --kernel-trace only) of bench.py; means per dispatch and per wave for every",
+            "# launch shape with >= 20 dispatches.  FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE tallies 64 B per",
+            "# 128-B request: read bytes = 2 x FETCH_SIZE KiB (MI355X_MICROARCH.md, HBM).  SQ_* cycle counters are quad-cycles.",
+            "kernel,grid_threads,dispatches,counter,per_dispatch,per_wave"]
+summary = {}
+for (label, grid), cs in sorted(agg.items()):
+    n = len(cs["duration_ns"])
+    if n < 20:
         continue
-    vals = list(roll.values())
-    big, small = split_rollout([e["duration_ns"] for e in vals])
-    L = [e for e, s in zip(vals, big) if s]
-    S = [e for e, s in zip(vals, small) if s]
-    P = list(step.values())
-    mean = lambda rows, k: float(np.mean([e[k] for e in rows])) if rows else float("nan")
-    for k in sorted(L[0]):
-        a, b, c = mean(L, k), mean(S, k), mean(P, k)
-        pmc_rows.append(f"{k},{a:.6g},{a/2048:.6g},{b:.6g},{b/2048:.6g},{c:.6g},{c/2048:.6g}")
-        if k in ("FETCH_SIZE", "WRITE_SIZE"):
-            traffic[k] = {"T20_KiB": a, "T1_KiB": b, "step_KiB": c}
+    waves = int(grid) // 64
+    for c in sorted(cs):
+        mean = float(np.mean(cs[c]))
+        pmc_rows.append(f"\"{label}\",{grid},{len(cs[c])},{c},{mean:.6g},{mean / waves:.6g}")
+        summary[(label, grid, c)] = mean
 open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w").write("\n".join(pmc_rows) + "\n")
-if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
-    total = lambda key: int((2 * traffic["FETCH_SIZE"][key] + traffic["WRITE_SIZE"][key]) * 1024)
-    out = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), profiles/{tag}_pmc_summary.csv",
-           "correction": "gfx950: read bytes = 2 x FETCH_SIZE (64 B tallied per 128-B request); WRITE_SIZE exact",
-           "rollout_T20_bytes_per_launch": total("T20_KiB"),
-           "single_step_bytes_per_launch": total("T1_KiB"),
-           "batch": 65536, "max_points": 20, "dim": 3}
-    if not np.isnan(traffic["FETCH_SIZE"]["step_KiB"]):
-        out["boundary_step_bytes_per_launch"] = total("step_KiB")
-    json.dump(out, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1)
-    print(out)
-print("\n".join(lines[:14]))
+
+
+def find(pat_grid, suffix, counter):
+    pat, grid = pat_grid
+    for (label, g, c), v in summary.items():
+        if g == grid and c == counter and pat.search(label) and label.endswith(suffix):
+            return v
+    return None
+
+
+def traffic(pat_grid, suffix=""):
+    f, w = find(pat_grid, suffix, "FETCH_SIZE"), find(pat_grid, suffix, "WRITE_SIZE")
+    return None if f is None or w is None else int((2 * f + w) * 1024)
+
+
+out = {"source": f"rocprofv3 --pmc passes (separate runs), profiles/{tag}_pmc_summary.csv",
+       "correction": "gfx950: read bytes = 2 x FETCH_SIZE (64 B tallied per 128-B request); WRITE_SIZE exact",
+       "batch": 65536, "max_points": 20, "dim": 3,
+       "rollout_T20_bytes_per_launch": traffic(ROLLOUT, "[T=20]"),
+       "rollout_T20_valu_insts_per_launch": find(ROLLOUT, "[T=20]", "SQ_INSTS_VALU"),
+       "single_step_bytes_per_launch": traffic(ROLLOUT, "[T=1]"),
+       "boundary_step_bytes_per_launch": traffic(STEP),
+       "boundary_step_valu_insts_per_launch": find(STEP, "", "SQ_INSTS_VALU"),
+       "boundary_step_wait_any_frac": (find(STEP, "", "SQ_WAIT_ANY") or 0) / (find(STEP, "", "SQ_WAVE_CYCLES") or 1),
+       "config3_step_bytes_per_launch": traffic(STEP3)}
+
+# ---- share of the GPU time of the search workload spent in this package's HIP kernels ----------------------------
+sstats = first("search/**/*kernel_stats.csv")
+if sstats:
+    shutil.copy(sstats, os.path.join(dst, f"{tag}_search_kernel_stats.csv"))
+    tot = ours = 0.0
+    for r in csv.DictReader(open(sstats)):
+        t = float(r["TotalDurationNs"])
+        tot += t
+        if "hk::" in r["Name"]:
+            ours += t
+    if tot:
+        out["search_hip_kernel_share"] = ours / tot
+out = {k: v for k, v in out.items() if v is not None}
+json.dump(out, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
+print("\n".join(lines[:16]))

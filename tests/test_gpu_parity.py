@@ -237,9 +237,52 @@ def test_random_vs_oracle_fast_specs(spec):
     m, d = spec
     assert ops.has_fast_path(m, d)
     rng = np.random.default_rng(100 * m + d)
-    _check_all_ops(rng, m, d, np.float32, force_generic=False, b=97 if m < 50 else 70)  # two lanes per game
-    with ops.forced(A.HK_FLAG_FORCE_ONE_LANE):
+    _check_all_ops(rng, m, d, np.float32, force_generic=False, b=97 if m < 50 else 70)  # the default kernels
+    for lanes in (A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_TWO_LANES):
+        with ops.forced(lanes):
+            _check_all_ops(rng, m, d, np.float32, force_generic=False, b=97 if m < 50 else 70)
+
+
+QUAD_SPECS = [(10, 3), (20, 3), (20, 4), (50, 4)]  # hk::quad_kernel (four lanes per game): hk_step
+
+
+@pytest.mark.parametrize("spec", QUAD_SPECS)
+def test_random_vs_oracle_four_lane_step(spec):
+    """hk::quad_kernel forced for every hk_step it can serve: all semantics / stage masks / paddings of
+    _check_all_ops, then the compiled action layouts (f32 mask + i32 / i64 / f32 axis, class ids) with out-of-range and
+    non-integral axes, dense states (every row live: the many-slot paths), and batches that end inside a wave."""
+    m, d = spec
+    rng = np.random.default_rng(7 * m + d)
+    with ops.forced(A.HK_FLAG_FORCE_FOUR_LANES):
         _check_all_ops(rng, m, d, np.float32, force_generic=False, b=97 if m < 50 else 70)
+    for b in (1, 17, 1000):
+        for dense in (False, True):
+            p = CO.generate_points(b, m, d, 20, 5) if not dense else \
+                rng.integers(0, 20, (b, m, d)).astype(np.float32)
+            cls = rng.integers(0, 2 ** d - d - 1, b).astype(np.int32)
+            ax = rng.integers(0, d, b).astype(np.int32)
+            if b > 8:
+                ax[3], ax[5] = d, -1
+            mask = NO.decode_class(cls, d).astype(np.float32)
+            for sem in ("jax", "torch", "list"):
+                fl_o = CO.flags_of(sem=sem, noop_if_invalid=sem != "jax", ignore_ended=sem == "torch")
+                fl_p = ops.make_flags(sem, sem != "jax", sem == "torch") | A.HK_FLAG_FORCE_FOUR_LANES
+                for stages in (7, 15):
+                    want = CO.step(p, cls, ax, stages=stages, flags=fl_o)
+                    axes = [dev(ax), dev(ax).long(), dev(ax).float()]
+                    if b > 8:
+                        axes[2] = axes[2].clone()
+                        axes[2][7] = 0.5  # a non-integral axis matches nothing
+                        want_f = CO.step(p, cls, np.where(np.arange(b) == 7, -1, ax).astype(np.int32), stages=stages, flags=fl_o)
+                    else:
+                        want_f = want
+                    for coords in (dev(cls), dev(mask)):
+                        for ai, a in enumerate(axes):
+                            got = ops.step(dev(p), coords, a, stages=stages, flags=fl_p,
+                                           want=("done", "prev_done", "reward", "num_points"))
+                            ref = want_f if ai == 2 else want
+                            for k in ("points", "done", "prev_done", "reward", "num_points"):
+                                assert np.array_equal(host(got[k]), ref[k]), (k, spec, b, dense, sem, stages, ai)
 
 
 @pytest.mark.parametrize("spec", [(20, 3), (10, 3), (8, 4), (4, 3)])
