@@ -115,9 +115,10 @@ __device__ inline void duo_store_slab(const float* lds, float* out, int64_t out_
 
 // ---- image <-> registers ----------------------------------------------------------------------------------
 // the set bits of `mask` in ascending order are the game's live rows; lane h takes the ranks h, h + 2, ...
-template <int M, int CH, int D>
+// (SB: compile-time bound of the slots touched -- the staircase of rollout loops below knows it per level)
+template <int M, int CH, int D, int SB = CH>
 __device__ __forceinline__ void duo_gather(float (&q)[CH * D], const float* mine, uint32_t mask, int smax, int h) {
-  unrolled_while<0, CH>([&](auto sc) {
+  unrolled_while<0, SB>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
     if (s >= smax) return false;
     const bool has0 = mask != 0;
@@ -138,10 +139,10 @@ __device__ __forceinline__ void duo_gather(float (&q)[CH * D], const float* mine
 }
 
 // the lane's live rows back to their slots; returns the mask of the GAME's slots still alive
-template <int M, int CH, int D>
+template <int M, int CH, int D, int SB = CH>
 __device__ __forceinline__ uint32_t duo_scatter(const float (&q)[CH * D], float* mine, uint32_t mask, int smax, int h) {
   uint32_t alive = 0;
-  unrolled_while<0, CH>([&](auto sc) {
+  unrolled_while<0, SB>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
     if (s >= smax) return false;
     const bool has0 = mask != 0;
@@ -327,6 +328,18 @@ __device__ __forceinline__ void duo_scatter_ranked(const float (&q)[CH * D], flo
   });
 }
 
+// The buckets of slots per lane (1..6, 8, 10, ...) from the top down: f(NB, LO) for every bucket NB with the next
+// smaller one LO (0 below the first)
+template <int NB>
+struct DuoLevels {
+  static constexpr int kLo = (NB <= 6) ? NB - 1 : NB - 2;
+  template <typename F>
+  static __device__ __forceinline__ void run(F&& f) {
+    f(std::integral_constant<int, NB>{}, std::integral_constant<int, kLo>{});
+    if constexpr (kLo >= 1) DuoLevels<kLo>::run(f);
+  }
+};
+
 // The policy stream of a pair: Philox block b (steps 2b, 2b + 1) is computed by the lane with (b & 1) == h only
 // -- one Philox per lane per FOUR steps -- and its two words reach the partner through DPP.
 struct DuoPolicyCache {
@@ -489,9 +502,66 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   else
     asm volatile("" : "+s"(count_slot), "+s"(count_stride), "+s"(step0), "+s"(seed), "+s"(host_policy),
                  "+s"(agent_policy));
+  if constexpr (MODE == kModeRollout) {
+    // ---- plain rollouts: a STAIRCASE of loops, one per bucket of slots per lane, entered from the top down.  smax
+    // never grows, so the wave walks down the stairs once; each loop is straight-line for its own bucket -- no
+    // per-step dispatch over the buckets, and only the slots the bucket covers are loop-carried registers (a single
+    // loop over all buckets moves the whole row array at every back edge: 16 v_mov_b64 per step at (20,3)). -------
+    static_assert(CH <= 6 || CH % 2 == 0, "bucket ladder: 1..6, then even numbers");
+    int t = 0;
+    bool stop = false;
+    DuoLevels<CH>::run([&](auto nbc, auto loc) {
+      constexpr int NB = decltype(nbc)::value, LO = decltype(loc)::value;
+      while (t < nsteps && (smax > LO || LO == 0) && !stop) {  // (a wave of empty games has smax 0: the last loop's)
+        int axis, cls;
+        uint32_t mask, ra, rb;
+        duo_policy_words(gg, step0 + (uint32_t)t, seed, dcache, h, ra, rb);
+        policy_from_words<D>(ra, rb, host_policy, agent_policy, cls, axis, mask, 0);
+        const unsigned st = (end_sort && t + 1 == nsteps) ? (stages & ~(unsigned)HK_STAGE_RESCALE) : stages;
+        rescale_pending = end_sort && t + 1 == nsteps && (stages & HK_STAGE_RESCALE);
+        np = d_stages<CH, D, NB, true>(q, c, axis, np, h, flags, st, mask);
+        if (!active) np = 2;
+        const bool done = np < 2;
+        if (done && length < 0) length = t + 1;
+        const unsigned long long bd = __ballot(leader && done);
+        if (count_slot && lane == 0) count_add(count_slot + (size_t)(t + 1) * count_stride, (uint32_t)__popcll(bd));
+        if constexpr (NB == 1) {
+          // Fixed point: a game that is down to ONE point sitting at the origin (or to none) does not change any
+          // more -- whatever the subset and the axis: the shift adds zeros, reposition / rescale find nothing to move,
+          // the Newton stage has nothing to compare.  Once every game of the wave is there (a game reaches it one
+          // step after it ends when reposition is on; the mean game lasts 5 steps, the longest of 32 about 13), the
+          // rest of the episode is the finished-game counts, added in closed form.
+          if (bd == __ballot(leader) && t + 1 < nsteps) {
+            bool still = true;  // (one slot per lane: it holds the game's point, a hole, or nothing)
+#pragma unroll
+            for (int k = 0; k < D; ++k) still &= (q[k] == 0.0f);
+            still |= !(q[0] < INFINITY);
+            if (!__any(active && !still)) {
+              if (count_slot && lane == 0)
+                for (int tt = t + 1; tt < nsteps; ++tt)
+                  count_add(count_slot + (size_t)(tt + 1) * count_stride, (uint32_t)__popcll(bd));
+              stop = true;
+            }
+          }
+        } else {
+          // re-deal the rows when the widest game of the wave fits fewer slots per lane
+          if (t + 1 < nsteps && !__any(active && ((np + 1) >> 1) >= smax)) {
+            __syncthreads();
+            gmask = duo_scatter<M, CH, D, NB>(q, mine, gmask, smax, h);
+            __syncthreads();
+            const int sprev = smax;
+            nmax = wave_max(active ? np : 0, 2 * smax - 2);
+            smax = (nmax + 1) >> 1;
+            duo_gather<M, CH, D, NB>(q, mine, gmask, sprev, h);  // slots [smax, sprev) become holes again
+          }
+        }
+        ++t;
+      }
+    });
+  }
   const bool want_obs = kRec && prm.obs_out != nullptr;
   const bool want_records = kRec && (prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out);
-  for (int t = 0; t < nsteps; ++t) {
+  for (int t = 0; MODE != kModeRollout && t < nsteps; ++t) {  // single steps and recording rollouts
     int axis = axis_in, cls = 0;
     if (want_obs) {  // state before the step: rebuild the image, store it coalesced
       __syncthreads();
