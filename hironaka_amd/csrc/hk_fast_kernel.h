@@ -510,7 +510,59 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
     asm volatile("" : "+s"(count_slot), "+s"(count_stride), "+s"(step0), "+s"(seed), "+s"(host_policy),
                  "+s"(agent_policy));
   bool rescale_pending = false;
-  for (int t = 0; t < nsteps; ++t) {
+  // (Zeillinger's host scans all pairs of rows before every step: its rollouts keep the single loop below)
+  const bool staircase = MODE == kModeRollout && (HOT || host_policy != HK_HOST_ZEILLINGER);
+  if (MODE == kModeRollout && staircase) {
+    // ---- plain rollouts: a STAIRCASE of loops, one per bucket of rows, entered from the top down (nmax never
+    // grows): each loop is straight-line for its bucket -- no per-step dispatch over the buckets, and only the rows
+    // the bucket covers are loop-carried registers (see hk_duo_kernel.h) --------------------------------------------
+    static_assert(G::C <= 8 || G::C % 2 == 0, "bucket ladder: 1..8, then even numbers");
+    int t = 0;
+    bool stop = false;
+    RowLevels<G::C>::run([&](auto nbc, auto loc) {
+      constexpr int NB = decltype(nbc)::value, LO = decltype(loc)::value;
+      while (t < nsteps && (nmax > LO || LO == 0) && !stop) {  // (a wave of empty games has nmax 0: the last loop's)
+        int axis, cls;
+        uint32_t mask;
+        fast_policy<D>(seed, host_policy, agent_policy, gg, step0 + (uint32_t)t, pcache, cls, axis, mask, 0);
+        // (end_sort: the last step's rescale waits until the rows are ranked, after the loop)
+        const unsigned st = (end_sort && t + 1 == nsteps) ? (stages & ~(unsigned)HK_STAGE_RESCALE) : stages;
+        rescale_pending = end_sort && t + 1 == nsteps && (stages & HK_STAGE_RESCALE);
+        np = b_stages<G::C, D, NB, true>(q, c, axis, np, flags, st, mask);
+        if (!active) np = 2;
+        const bool done = np < 2;
+        if (done && length < 0) length = t + 1;
+        const unsigned long long bd = __ballot(active && done);
+        if (count_slot && lane == 0) count_add(count_slot + (size_t)(t + 1) * count_stride, (uint32_t)__popcll(bd));
+        if constexpr (NB == 1) {
+          // Fixed point (see hk_duo_kernel.h): once every game of the wave is down to one point at the origin (or
+          // none) nothing changes any more; the rest of the episode is the finished-game counts, in closed form.
+          if (bd == __ballot(active) && t + 1 < nsteps) {
+            bool still = true;
+#pragma unroll
+            for (int k = 0; k < D; ++k) still &= (q[k] == 0.0f);
+            still |= !(q[0] < INFINITY);
+            if (!__any(active && !still)) {
+              if (count_slot && lane == 0)
+                for (int tt = t + 1; tt < nsteps; ++tt)
+                  count_add(count_slot + (size_t)(tt + 1) * count_stride, (uint32_t)__popcll(bd));
+              stop = true;
+            }
+          }
+        } else {
+          // re-gather when the widest game of the wave got narrower (removed rows are holes until then)
+          if (t + 1 < nsteps && !__any(active && np >= nmax)) {
+            gmask = scatter_rows<M, G::C, D, NB>(q, mine, gmask, nmax);
+            const int nprev = nmax;
+            nmax = wave_max(active ? np : 0, nmax - 1);
+            gather_rows<M, G::C, D, NB>(q, mine, gmask, nprev);  // rows [nmax, nprev) become holes again
+          }
+        }
+        ++t;
+      }
+    });
+  }
+  for (int t = 0; !staircase && t < nsteps; ++t) {  // single steps, recording rollouts, the aux step modes, Zeillinger
     int axis = -1, cls = 0;
     uint32_t mask = 0;  // rollouts: the policy's subset as a 0/1 mask (the shift as selects, b_shift_mask)
     if (kRoll) {

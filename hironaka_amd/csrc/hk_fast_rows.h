@@ -40,9 +40,10 @@ __device__ inline int mask_first(uint32_t m) { return __ffs(m) - 1; }
 __device__ inline int mask_first(unsigned long long m) { return __ffsll(m) - 1; }
 
 // rows of the set bits of `mask`, ascending, into q[0..n); q[n..nmax) := +inf
-template <int M, int C, int D>
+// (SB: compile-time bound of the rows touched -- the staircase of rollout loops knows it per level)
+template <int M, int C, int D, int SB = C>
 __device__ __forceinline__ void gather_rows(float (&q)[C * D], const float* mine, MaskT<M> mask, int nmax) {
-  unrolled_while<0, C>([&](auto rc) {
+  unrolled_while<0, SB>([&](auto rc) {
     constexpr int r = decltype(rc)::value;
     if (r >= nmax) return false;
     const bool has = mask != 0;
@@ -59,10 +60,10 @@ __device__ __forceinline__ void gather_rows(float (&q)[C * D], const float* mine
 }
 
 // live rows of q back to their slots; returns the mask of the slots still alive
-template <int M, int C, int D>
+template <int M, int C, int D, int SB = C>
 __device__ __forceinline__ MaskT<M> scatter_rows(const float (&q)[C * D], float* mine, MaskT<M> mask, int nmax) {
   MaskT<M> alive = 0;
-  unrolled_while<0, C>([&](auto rc) {
+  unrolled_while<0, SB>([&](auto rc) {
     constexpr int r = decltype(rc)::value;
     if (r >= nmax) return false;
     const bool has = mask != 0;
@@ -372,6 +373,18 @@ struct StagesFor {
       if (nmax <= NB) return b_stages<C, D, NB, BIN>(q, c, axis, np, flags, stages, cmask);
       return StagesFor<C, D, kNext, BIN>::run(q, nmax, c, axis, np, flags, stages, cmask);
     }
+  }
+};
+
+// The buckets of rows (1..8, 10, 12, ...) from the top down: f(NB, LO) for every bucket NB with the next smaller one
+// LO (0 below the first) -- the staircase of rollout loops (hk_fast_kernel.h, hk_duo_kernel.h)
+template <int NB>
+struct RowLevels {
+  static constexpr int kLo = (NB <= 8) ? NB - 1 : NB - 2;
+  template <typename F>
+  static __device__ __forceinline__ void run(F&& f) {
+    f(std::integral_constant<int, NB>{}, std::integral_constant<int, kLo>{});
+    if constexpr (kLo >= 1) RowLevels<kLo>::run(f);
   }
 };
 
