@@ -66,9 +66,17 @@ class HipPoints(PointsBase):
 
     # ---- what the trainers read -----------------------------------------------------------
     def exceed_threshold(self) -> bool:
+        """ListPoints / TensorPoints.exceed_threshold (core/tensor_points.py:57-63): a python bool, i.e. one host
+        synchronisation -- loops that must stay on the device use `exceed_threshold_tensor`"""
         if self.value_threshold is not None:
-            return bool(torch.max(self.points) >= self.value_threshold)
+            return bool(self.exceed_threshold_tensor())
         return False
+
+    def exceed_threshold_tensor(self) -> torch.Tensor:
+        """0-d bool tensor on the device (no synchronisation): any coordinate >= value_threshold"""
+        if self.value_threshold is None:
+            return torch.zeros((), dtype=torch.bool, device=self.points.device)
+        return torch.max(self.points) >= self.value_threshold
 
     def get_num_points(self) -> torch.Tensor:
         return ops.get_num_points(self.points).to(torch.int64)
