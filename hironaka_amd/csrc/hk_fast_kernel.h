@@ -710,6 +710,30 @@ inline int fast_hot_config(const Params& prm) {
   return kHotNone;
 }
 
+// The plain rollouts of a shape (three kernels: run-time configured, kHotJax, kHotTorch -- the staircase makes them the
+// longest to compile) live in a translation unit of their own (hk_fast_roll_spec.hip), the other modes in
+// hk_fast_spec.hip: the build's critical path halves.
+template <int M, int D>
+int launch_fast_roll_t(const Params& prm, unsigned grid, hipStream_t stream) {
+  const int hot = fast_hot_config(prm);
+  if (hot == kHotJax)
+    hipLaunchKernelGGL((fast_kernel<M, D, kModeRollout, kHotJax>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
+                       prm.in_stride, prm.batch, prm.games_per_block, prm);
+  else if (hot == kHotTorch)
+    hipLaunchKernelGGL((fast_kernel<M, D, kModeRollout, kHotTorch>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
+                       prm.in_stride, prm.batch, prm.games_per_block, prm);
+  else
+    hipLaunchKernelGGL((fast_kernel<M, D, kModeRollout>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
+                       prm.in_stride, prm.batch, prm.games_per_block, prm);
+  return launch_status();
+}
+
+#ifndef HK_FAST_ROLL_TU
+#define HK_X(M_, D_) extern template int launch_fast_roll_t<M_, D_>(const Params&, unsigned, hipStream_t);
+HK_FAST_SPECS(HK_X)
+#undef HK_X
+#endif
+
 template <int M, int D>
 int launch_fast_t(Params prm, hipStream_t stream) {
   prm.games_per_block = fast_games_per_block(prm);
@@ -727,15 +751,8 @@ int launch_fast_t(Params prm, hipStream_t stream) {
                                         prm.r_done_out || prm.r_reward_out))
     hipLaunchKernelGGL((fast_kernel<M, D, kModeRolloutRec>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
                        prm.in_stride, prm.batch, prm.games_per_block, prm);
-  else if (prm.mode == kModeRollout && fast_hot_config(prm) == kHotJax)
-    hipLaunchKernelGGL((fast_kernel<M, D, kModeRollout, kHotJax>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
-                       prm.in_stride, prm.batch, prm.games_per_block, prm);
-  else if (prm.mode == kModeRollout && fast_hot_config(prm) == kHotTorch)
-    hipLaunchKernelGGL((fast_kernel<M, D, kModeRollout, kHotTorch>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
-                       prm.in_stride, prm.batch, prm.games_per_block, prm);
   else if (prm.mode == kModeRollout)
-    hipLaunchKernelGGL((fast_kernel<M, D, kModeRollout>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
-                       prm.in_stride, prm.batch, prm.games_per_block, prm);
+    return launch_fast_roll_t<M, D>(prm, grid, stream);
   else
     hipLaunchKernelGGL((fast_kernel<M, D, kModeGenerate>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
                        prm.in_stride, prm.batch, prm.games_per_block, prm);
