@@ -946,13 +946,10 @@ inline bool quad_supported(const Params& prm, int dtype) {
   return false;
 }
 
-// where the four-lane kernel is the default choice (measured, scripts/probe_quad.py): the large games at any batch
-// ((50,4) x 262 144: 94 us against the team kernel's 113); the small ones while the one-lane kernel (64 games per
-// wave) would leave SIMDs short of a third wave -- beyond that its longer streams win ((20,3) x 524 288: 45.6 vs 47 us)
-inline bool quad_default(const Params& prm, int simds) {
-  if (prm.m * prm.d > 128) return true;
-  return (int64_t)prm.batch <= (int64_t)3 * kWave * simds;
-}
+// where the four-lane kernel is the default choice: everywhere it applies (scripts/probe_crossover.py: ahead of the
+// one-lane kernel from 32 768 to 524 288 games on (10,3), (20,3), (20,4) -- e.g. (20,3): 6.0 vs 11.3 us at 32 768,
+// 44.9 vs 52.7 us at 524 288 -- and of the team kernel on (50,4): 94 vs 113 us at 262 144)
+inline bool quad_default(const Params&, int) { return true; }
 
 #ifndef HK_SPEC_TU
 #define HK_X(M_, D_) extern template int launch_quad_t<M_, D_>(Params, hipStream_t);
