@@ -238,7 +238,14 @@ def action_wrapper(policy_value_fn: Callable, dimension: Optional[int] = None) -
         out, _ = masked_action(x, *args, **kwargs)
         return torch.nn.functional.one_hot(torch.argmax(out, dim=-1), out.shape[-1]).to(torch.float32)
 
+    def index_fn(x: torch.Tensor, *args, **kwargs) -> torch.Tensor:
+        """the chosen action as an index [B] -- what `recurrent_fn` would recover from the one-hot array with another
+        argmax (it uses this shortcut when the opponent offers it: three launches per simulation less)"""
+        out, _ = masked_action(x, *args, **kwargs)
+        return torch.argmax(out, dim=-1)
+
     wrapped_action_fn.__name__ = _name_of(policy_value_fn)
+    wrapped_action_fn.index_fn = index_fn
     return wrapped_action_fn
 
 

@@ -40,6 +40,7 @@ def get_recurrent_fn_for_role(role: str, role_fn: Callable, opponent_action_fn: 
     elif role == "agent":
         take = get_take_actions(role="agent", spec=spec, rescale_points=rescale_points, reposition=reposition)
         decode_one_hot = get_batch_decode_from_one_hot(d)
+        batch_decode_cls = get_batch_decode(d)
     else:
         raise ValueError(f"role must be either 'host' or 'agent'. Got {role}.")
 
@@ -55,21 +56,29 @@ def get_recurrent_fn_for_role(role: str, role_fn: Callable, opponent_action_fn: 
             discounts[key_] = torch.full((observations.shape[0],), discount, dtype=dtype, device=observations.device)
         return discounts[key_]
 
+    # an opponent built by `action_wrapper` also offers its choice as an index: no one-hot round trip
+    opponent_index_fn = getattr(opponent_action_fn, "index_fn", None)
+
     def recurrent_fn(params, key, actions: torch.Tensor, observations: torch.Tensor):
         role_fn_args, opponent_fn_args = params
         if role == "host":
             # host acts (class ids -> masks), the agent answers, then the step happens
             coords = batch_decode(actions, dtype)
-            opp = opponent_action_fn(make_agent_obs(observations, coords).to(dtype), *opponent_fn_args, key=key)
-            axis = torch.argmax(opp, dim=1)
+            agent_obs = make_agent_obs(observations, coords).to(dtype)
+            if opponent_index_fn is not None:
+                axis = opponent_index_fn(agent_obs, *opponent_fn_args, key=key)
+            else:
+                axis = torch.argmax(opponent_action_fn(agent_obs, *opponent_fn_args, key=key), dim=1)
             res = take(observations, coords, axis, want=want, reward_sign=sign or 1.0)
             next_observations = res["points"].to(dtype)
         else:
             # the agent's axis finishes the move first; the host then answers on the new points
             res = take(observations, None, actions, want=want, reward_sign=sign or 1.0)
             updated = res["points"]
-            opp = opponent_action_fn(updated.to(dtype), *opponent_fn_args, key=key)
-            next_coords = decode_one_hot(opp, dtype)
+            if opponent_index_fn is not None:
+                next_coords = batch_decode_cls(opponent_index_fn(updated.to(dtype), *opponent_fn_args, key=key), dtype)
+            else:
+                next_coords = decode_one_hot(opponent_action_fn(updated.to(dtype), *opponent_fn_args, key=key), dtype)
             next_observations = make_agent_obs(updated, next_coords).to(dtype)
         rewards = res["reward"] if sign is not None else reward_fn(res["done"], res["prev_done"])
         policy_prior, value_prior = role_fn(next_observations, *role_fn_args, key=key)

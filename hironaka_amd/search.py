@@ -158,7 +158,8 @@ def _run_search(params, rng_key, root: RootFnOutput, gumbel: torch.Tensor, inval
                                      parent.data_ptr(), action.data_ptr(), node.data_ptr(), _stream(gumbel)),
                   "hk_search_select")
             embedding = tree.embeddings[rows, parent]  # int32 indices are fine
-            step, next_embedding = recurrent_fn(params, simulation_key(rng_key, sim), action.long(), embedding)
+            # (actions travel as int32, as in mctx; the HIP operators take them as they are)
+            step, next_embedding = recurrent_fn(params, simulation_key(rng_key, sim), action, embedding)
             tree.embeddings[rows, node] = next_embedding.to(tree.embeddings.dtype)
             logits = step.prior_logits.to(torch.float32).contiguous()
             value = step.value.to(torch.float32).contiguous()

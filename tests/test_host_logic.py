@@ -33,3 +33,29 @@ def test_details_match_reference_loop(seed):
     # the reference's quirk: games that finish on the very last move are in no bin
     assert sum(got) == total - int((length == L - 1).sum())
     assert rho_from_details(got) == pytest.approx(sum(want[1:]) / sum(i * n for i, n in enumerate(want)))
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher: N ranks as a CHILD process tree (torch.distributed.run on
+    127.0.0.1), the same arguments passed through, the children's status returned -- and nothing of it touches the GPU
+    in the parent."""
+    import argparse
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 3)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    rc = bench.spawn_ranks(argparse.Namespace(gpus=4))
+    cmd = seen["cmd"]
+    assert rc == 3 and cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert bench.algorithmic_bytes_per_step(20, 3) == 501 and bench.algorithmic_bytes_per_step(50, 4) == 1625
