@@ -681,7 +681,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kBig ? 2 : 4)) void q
   for (int e = 0; e < R * D; ++e) q[e] = INFINITY;
   unrolled_while<0, R>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
-    if (G::kBig && s >= smax) return false;
+    if (s >= smax && (G::kBig || s >= 2)) return false;  // (small games: the first two slots without a branch)
     const bool has = kQuad * s + j < np;
     const float* src = cmine + (kQuad * s + j < M ? kQuad * s + j : 0) * G::CW;
     if constexpr (G::kBig) {
