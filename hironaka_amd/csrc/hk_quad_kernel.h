@@ -383,6 +383,79 @@ __device__ __forceinline__ void qd_ranks_first(const float (&q)[R * D], int (&ra
   }
 }
 
+// observation features (jax/util.py:186-197, last coordinate primary; `coord0`: core/tensor_points.py:72-74, coordinate
+// 0 alone): position of each of the lane's rows in descending key order, rows with EQUAL keys in row order (their
+// compact rank: 4 s + lane).  Every pair of the game once -- own slots' triangle, ALL pairs with the lane one up, the
+// pairs a <= b with the lane two up, as in qd_newton -- and what a lane counts for a partner's rows travels back.
+template <int D>
+__device__ __forceinline__ void qd_key_cmp(const float* a, const float* b, bool coord0, bool& gt, bool& eq) {
+  gt = false;
+  eq = true;
+#pragma unroll
+  for (int kk = 0; kk < D; ++kk) {
+    const int k = D - 1 - kk;
+    gt |= eq && (a[k] > b[k]);
+    eq &= (a[k] == b[k]);
+  }
+  if (coord0) {
+    gt = a[0] > b[0];
+    eq = a[0] == b[0];
+  }
+}
+
+template <int R, int D, int NB>
+__device__ __forceinline__ void qd_ranks_stable(const float (&q)[R * D], int j, bool coord0, int (&rank)[R]) {
+  int o1[NB], o2[NB];  // rows of mine that come before the partner's slot b
+#pragma unroll
+  for (int s = 0; s < R; ++s) rank[s] = 0;
+#pragma unroll
+  for (int s = 0; s < NB; ++s) o1[s] = o2[s] = 0;
+  bool live[NB];
+#pragma unroll
+  for (int s = 0; s < NB; ++s) live[s] = q[s * D] < INFINITY;
+#pragma unroll
+  for (int a = 0; a + 1 < NB; ++a)
+#pragma unroll
+    for (int b = a + 1; b < NB; ++b) {  // own slots: a is the earlier row
+      bool gt, eq;
+      qd_key_cmp<D>(&q[b * D], &q[a * D], coord0, gt, eq);  // b first iff its key is strictly greater
+      rank[a] += (gt && live[b]) ? 1 : 0;
+      rank[b] += (!gt && live[a]) ? 1 : 0;
+    }
+  const bool late1 = j == 3, late2 = j >= 2;  // on the diagonal the partner's row is the earlier one
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    float p1[D], p2[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      p1[k] = qperm<kQuadUp1>(q[b * D + k]);
+      p2[k] = qperm<kQuadUp2>(q[b * D + k]);
+    }
+    const bool l1 = p1[0] < INFINITY, l2 = p2[0] < INFINITY;
+#pragma unroll
+    for (int a = 0; a < NB; ++a) {
+      {  // the lane one up: all pairs; its row is the earlier one iff b < a, or b == a on lane 3
+        bool gt, eq;
+        qd_key_cmp<D>(p1, &q[a * D], coord0, gt, eq);
+        const bool other_first = gt || (eq && (b < a || (b == a && late1)));
+        rank[a] += (other_first && l1) ? 1 : 0;
+        o1[b] += (!other_first && live[a]) ? 1 : 0;
+      }
+      if (a <= b) {  // the lane two up: pairs a < b (it does the mirror image); the diagonal is counted ONCE, by the
+        bool gt, eq;   // lower lane of the two (counts add up, unlike the verdicts of the domination test)
+        qd_key_cmp<D>(p2, &q[a * D], coord0, gt, eq);
+        const bool mine_counts = a < b || !late2;
+        const bool other_first = gt;  // (equal keys: my row is the earlier one wherever this pair is counted)
+        rank[a] += (mine_counts && other_first && l2) ? 1 : 0;
+        o2[b] += (mine_counts && !other_first && live[a]) ? 1 : 0;
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NB; ++s)  // what the lane one DOWN and the lane two up counted for my slot s
+    rank[s] += qperm_i<kQuadUp3>(o1[s]) + qperm_i<kQuadUp2>(o2[s]);
+}
+
 // one transition on slots [0, NB) of the four lanes; returns the GAME's number of live rows.  `sorted` (list
 // semantics): the survivors are ranked right after the Newton stage, before a rescale could round two keys together.
 template <int M, int CW, int R, int D, int NB>
@@ -398,6 +471,8 @@ __device__ __forceinline__ int qd_stages(float (&q)[R * D], const float (&c)[D],
       if (sorted) qd_ranks_first<R, D, NB>(q, rank);
   }
   if (stages & HK_STAGE_RESCALE) qd_rescale<R, D, NB>(q, flags);
+  if constexpr (NB <= kQuadDppSlots)  // the observation features are sorted AFTER their rescale
+    if (stages & kStageFeatureSorts) qd_ranks_stable<R, D, NB>(q, j, (stages & kStageFeatureSort0) != 0, rank);
   int n = 0;
 #pragma unroll
   for (int r = 0; r < NB; ++r) n += (q[r * D] < INFINITY) ? 1 : 0;
@@ -729,10 +804,12 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kBig ? 2 : 4)) void q
   const bool prev_done = np < 2;
   const int np_before = np;
   // list semantics / COMPACT_SORTED (small games, run-time configured kernels only): sorted + compacted output
-  const bool sorted = !G::kBig && HOT == kHotNone && (stages & HK_STAGE_NEWTON) &&
-                      ((flags & HK_SEM_MASK) == HK_SEM_LIST || (flags & HK_FLAG_COMPACT_SORTED));
+  const bool list_sorted = !G::kBig && HOT == kHotNone && (stages & HK_STAGE_NEWTON) &&
+                           ((flags & HK_SEM_MASK) == HK_SEM_LIST || (flags & HK_FLAG_COMPACT_SORTED));
+  // ... or the observation features: rows in descending key order (hk_get_features / hk_get_features_torch)
+  const bool sorted = list_sorted || (!G::kBig && HOT == kHotNone && (stages & kStageFeatureSorts));
   int rank[R];
-  np = QuadStagesFor<M, D, 1>::run(q, smax, c, axis_in, np, j, flags, stages, cmine, sorted, rank);
+  np = QuadStagesFor<M, D, 1>::run(q, smax, c, axis_in, np, j, flags, stages, cmine, list_sorted, rank);
   const bool done = np < 2;
   if (leader) {
     if (prm.done_out) prm.done_out[g] = done;
@@ -933,7 +1010,8 @@ bool quad_ok_t(const Params& prm) {
 
 inline bool quad_supported(const Params& prm, int dtype) {
   if (dtype != HK_F32 || prm.mode != kModeStep) return false;
-  if (prm.class_out || (prm.stages & kStageFeatureSorts)) return false;
+  if (prm.class_out) return false;
+  if ((prm.stages & kStageFeatureSorts) && prm.m * prm.d > 128) return false;  // (the large games: team kernel)
   if (prm.coords_kind == HK_COORDS_IN_RECORD) return false;
   if (prm.flags & (HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_TEAM | HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES))
     return false;

@@ -1,15 +1,17 @@
-"""Dev probe: time hk_get_features (rescale + row sort, the observation transform in front of the network)."""
+"""Dev probe: hk_get_features / hk_get_features_torch timings (default dispatch vs the one-lane kernel)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from hironaka_amd import _abi as A
 from hironaka_amd import ops
 from probe_stages import timeit
 
-for b, m, d in ((65536, 20, 3), (8192, 20, 3), (262144, 50, 4)):
-    P = ops.generate_points(b, m, d, 20, seed=42)
-    cls = torch.randint(0, 2 ** d - d - 1, (b,), device="cuda", dtype=torch.int32)
-    ax = torch.randint(0, d, (b,), device="cuda", dtype=torch.int32)
-    Q = ops.step(P, cls, ax, stages=7)["points"]
-    for sc in (True, False):
-        t = timeit(lambda: ops.get_features(Q, scale_observation=sc), iters=20, reps=5)
-        print(f"get_features b={b} ({m},{d}) scale={sc}: {t:.1f} us")
+for m, d in ((20, 3), (10, 3), (20, 4)):
+    for b in (8192, 65536):
+        P = ops.generate_points(b, m, d, 20, seed=42)
+        for name, fn in (("get_features(scale)", lambda: ops.get_features(P, True)), ("get_features(raw)", lambda: ops.get_features(P, False)),
+                         ("get_features_torch", lambda: ops.get_features_torch(P))):
+            t = timeit(fn, iters=20, reps=20)
+            with ops.forced(A.HK_FLAG_FORCE_ONE_LANE):
+                t1 = timeit(fn, iters=20, reps=20)
+            print(f"({m},{d}) b={b:6d} {name:20s} default {t:7.2f} us   one-lane {t1:7.2f} us", flush=True)
