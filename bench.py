@@ -177,9 +177,13 @@ def main():
         """the trainer boundary: every rank ends up with all B*world final states"""
         if not distributed:
             return state
+        # HK_BENCH_GATHER=direct: the fully-connected point-to-point variant (distributed.all_gather_games_direct);
+        # default: RCCL's own all-gather
+        direct = os.environ.get("HK_BENCH_GATHER", "rccl") == "direct"
+        shard = hkdist.Shard(rank * b, b, world * b)
         if backend == "nccl":
-            return hkdist.all_gather_games(state)
-        return hkdist.all_gather_games(state.cpu())
+            return hkdist.all_gather_games(state, shard, direct=direct)
+        return hkdist.all_gather_games(state.cpu(), shard, direct=direct)
 
     def timed_replays(replay, min_seconds):
         """`replay()` enqueues one unit of work (graph replays) on the current stream.  Estimate its duration,

@@ -38,7 +38,7 @@ def shard_range(total_games: int, rank_: Optional[int] = None, world_: Optional[
     return Shard(start, size, total_games)
 
 
-def all_gather_games(local: torch.Tensor, shard: Optional[Shard] = None) -> torch.Tensor:
+def all_gather_games(local: torch.Tensor, shard: Optional[Shard] = None, direct: bool = False) -> torch.Tensor:
     """[B_local, ...] per rank -> [B_total, ...] on every rank, in global game order.  Equal shards use
     one all_gather_into_tensor; ragged shards are padded to the largest one first.  Without a `shard` the
     ranks first exchange their local sizes (one tiny all-gather), so ragged inputs take the padded path
@@ -46,6 +46,10 @@ def all_gather_games(local: torch.Tensor, shard: Optional[Shard] = None) -> torc
     w = world()
     if w == 1:
         return local
+    if direct:
+        if shard is None:
+            raise ValueError("the direct gather needs the Shard (every rank must know every shard's size)")
+        return all_gather_games_direct(local, shard)
     if shard is not None:
         sizes = [shard_range(shard.total, r, w).size for r in range(w)]
         if sizes[rank()] != local.shape[0]:
@@ -65,6 +69,38 @@ def all_gather_games(local: torch.Tensor, shard: Optional[Shard] = None) -> torc
     out = torch.empty((w * biggest, *local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, padded)
     return torch.cat([out[r * biggest: r * biggest + sizes[r]] for r in range(w)], dim=0)
+
+
+def all_gather_games_direct(local: torch.Tensor, shard: Shard) -> torch.Tensor:
+    """The same gather as FULLY-CONNECTED point-to-point transfers: every rank posts one send of its shard to and one
+    receive from every other rank in ONE batch (`dist.batch_isend_irecv` = a grouped send/recv in RCCL), i.e. the 7
+    xGMI links of an MI355X carry 7 shards concurrently instead of a ring forwarding them hop by hop (SURVEY.md
+    section 5 / 8(e): ~0.1 ms against ~0.7 ms for 15.7 MB per rank).  Ragged shards need no padding here.
+    Opt-in (`all_gather_games(..., direct=True)`): RCCL's own all-gather is the default and the only variant that
+    has run on hardware so far."""
+    w, r = world(), rank()
+    if w == 1:
+        return local
+    sizes = [shard_range(shard.total, k, w).size for k in range(w)]
+    starts = [shard_range(shard.total, k, w).start for k in range(w)]
+    if sizes[r] != local.shape[0]:
+        raise ValueError(f"rank {r} holds {local.shape[0]} games, its shard of {shard.total} is {sizes[r]}")
+    local = local.contiguous()
+    out = torch.empty((shard.total, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    out[starts[r]: starts[r] + sizes[r]] = local
+    ops = []
+    for k in range(w):
+        if k == r or sizes[k] == 0:
+            continue
+        ops.append(dist.P2POp(dist.irecv, out[starts[k]: starts[k] + sizes[k]], k))
+    for k in range(w):
+        if k == r or sizes[r] == 0:
+            continue
+        ops.append(dist.P2POp(dist.isend, local, k))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return out
 
 
 def all_gather_rollout(rollout: Sequence[torch.Tensor], shard: Optional[Shard] = None):

@@ -35,6 +35,8 @@ def _worker(rank, world, port, total, tmpdir):
         gathered = D.all_gather_games(torch.from_numpy(final), shard)
         # without a Shard the ranks exchange their sizes first: ragged inputs take the padded path too
         assert torch.equal(D.all_gather_games(torch.from_numpy(final)), gathered)
+        # ... and the fully-connected point-to-point variant gives the same tensor
+        assert torch.equal(D.all_gather_games(torch.from_numpy(final), shard, direct=True), gathered)
         try:
             D.all_gather_games(torch.from_numpy(final)[:-1], shard)
             raise AssertionError("a local batch that is not the rank's shard must be rejected")
@@ -50,10 +52,9 @@ def _worker(rank, world, port, total, tmpdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total", [64, 37])  # equal and ragged shards
-def test_two_rank_shards_equal_unsharded(tmp_path, total):
+@pytest.mark.parametrize("total,world", [(64, 2), (37, 2), (37, 3)])  # equal and ragged shards
+def test_two_rank_shards_equal_unsharded(tmp_path, total, world):
     from oracle import c_oracle as CO
-    world = 2
     mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / "out.npz")
     full = CO.generate_points(total, 10, 3, 20, 42)
