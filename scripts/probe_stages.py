@@ -11,7 +11,7 @@ def timeit(fn, iters=50, reps=20):
     with torch.cuda.stream(s):
         fn()
         torch.cuda.synchronize()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, stream=s):
             for _ in range(iters):
                 fn()
     torch.cuda.synchronize()
