@@ -81,30 +81,46 @@ struct QuadGeom {
 // in: LDS-DMA (global_load_lds_dwordx4: lane l of request `it` moves 16 B to image + (it * 64 + l) * 16 -- the image
 // IS the slab, no registers, no ds_write); chunks past a partial slab re-read its last chunk into image space that
 // nobody looks at.  Completion is the wave's vmcnt.
+// Addressing: `base` and `image` are wave-uniform (the wave index comes through readfirstlane), the lane adds an
+// unsigned 32-bit byte offset, and the requests of a lane differ by a compile-time constant: one VGPR offset for the
+// whole slab, the global address in SGPRs (saddr form), the rest in the instructions' immediate offsets -- the
+// per-request 64-bit address arithmetic was a third of the VALU instructions of the I/O skeleton, and at four waves
+// per SIMD every VALU instruction of the wave program is 16 cycles of the launch.
+// the instruction's immediate offset is 12 bits unsigned here (it moves the LDS address too); what exceeds it goes
+// into both base pointers
+constexpr int kDmaImm = 4096;
+template <int BYTES, int OFFSET>
+__device__ __forceinline__ void lds_dma(const float* src, float* dst) {
+  static_assert(BYTES == 16 || BYTES == 4, "request size");
+  if constexpr (BYTES == 16) __builtin_amdgcn_global_load_lds(src, dst, 16, OFFSET, 0);
+  else __builtin_amdgcn_global_load_lds(src, dst, 4, OFFSET, 0);
+}
+
 template <int M, int D>
 __device__ __forceinline__ void quad_slab_load(const float* base, float* image, int ngames, int lane) {
   using G = QuadGeom<M, D>;
-  if constexpr (G::W == 4) {
-    const int total = ngames * G::Q;
-#pragma unroll
-    for (int it = 0; it < G::QL; ++it) {
-      int q = lane + it * kWave;
-      const bool inside = q < kQuadGames * G::Q;  // (the last request may reach past the image: those lanes sit out)
-      q = q < total ? q : total - 1;
-      if ((it + 1) * kWave <= kQuadGames * G::Q || inside)
-        __builtin_amdgcn_global_load_lds(base + (int64_t)q * 4, image + it * kWave * 4, 16, 0, 0);
-    }
-  } else {  // records that are no multiple of 16 B: dword requests
-    constexpr int QF = (kQuadGames * G::N + kWave - 1) / kWave;
-    const int total = ngames * G::N;
-#pragma unroll
-    for (int it = 0; it < QF; ++it) {
-      int q = lane + it * kWave;
-      const bool inside = q < kQuadGames * G::N;
-      q = q < total ? q : total - 1;
-      if ((it + 1) * kWave <= kQuadGames * G::N || inside)
-        __builtin_amdgcn_global_load_lds(base + q, image + it * kWave, 4, 0, 0);
-    }
+  constexpr int CH = (G::W == 4) ? 4 : 1;                    // floats per request (16 B, or dwords when 16 does not divide a record)
+  constexpr int FULL = kQuadGames * G::N / CH;               // requests of a full slab
+  constexpr int QF = (FULL + kWave - 1) / kWave;             // ... per lane
+  const float* src = base + (unsigned)lane * CH;             // request `it`: + it * 64 * CH floats, in the immediate
+  const unsigned total = (unsigned)ngames * (G::N / CH);
+  // the immediate offset moves the global AND the LDS address: request `it` lands at image + (it * 64 + lane) * CH
+  if (ngames == kQuadGames) {  // (wave-uniform) every request but the last one whole
+    unrolled_while<0, QF>([&](auto ic) {
+      constexpr int it = decltype(ic)::value;
+      if ((it + 1) * kWave <= FULL || lane < FULL - it * kWave)
+        lds_dma<CH * 4, (it * kWave * CH * 4) % kDmaImm>(src + (it * kWave * CH * 4) / kDmaImm * (kDmaImm / 4),
+                                                        image + (it * kWave * CH * 4) / kDmaImm * (kDmaImm / 4));
+      return true;
+    });
+  } else {  // the batch's last slab: lanes past its end sit out
+    unrolled_while<0, QF>([&](auto ic) {
+      constexpr int it = decltype(ic)::value;
+      if ((unsigned)lane + it * kWave < total)
+        lds_dma<CH * 4, (it * kWave * CH * 4) % kDmaImm>(src + (it * kWave * CH * 4) / kDmaImm * (kDmaImm / 4),
+                                                        image + (it * kWave * CH * 4) / kDmaImm * (kDmaImm / 4));
+      return true;
+    });
   }
 }
 
@@ -115,22 +131,34 @@ __device__ __forceinline__ void quad_slab_store(const float* image, float* base,
   using G = QuadGeom<M, D>;
   using V = typename VecOf<G::W>::type;
   constexpr int B = G::kStoreBatch;
-  const int total = ngames * G::Q;
+  constexpr int FULL = kQuadGames * G::Q;
+  const unsigned total = (unsigned)ngames * G::Q;
+  const float* src = image + (unsigned)lane * G::W;  // chunk `it` of the lane: + it * 64 * W floats, an immediate
+  float* dst = base + (unsigned)lane * G::W;
+  const bool whole = ngames == kQuadGames;           // (wave-uniform)
 #pragma unroll
   for (int i0 = 0; i0 < G::QL; i0 += B) {
     V v[B];
 #pragma unroll
     for (int u = 0; u < B; ++u) {
-      int q = lane + (i0 + u) * kWave;
-      q = q < kQuadGames * G::Q ? q : kQuadGames * G::Q - 1;
-      v[u] = *reinterpret_cast<const V*>(image + q * G::W);
+      // (chunks past the image: the read lands in LDS nobody owns or past the allocation -- harmless, never stored)
+      if (i0 + u < G::QL) v[u] = *reinterpret_cast<const V*>(src + (i0 + u) * kWave * G::W);
     }
 #pragma unroll
     for (int u = 0; u < B; ++u) asm volatile("" : "+v"(v[u]));
+    if (whole) {
 #pragma unroll
-    for (int u = 0; u < B; ++u) {
-      const int q = lane + (i0 + u) * kWave;
-      if (i0 + u < G::QL && q < total) *reinterpret_cast<V*>(base + (int64_t)q * G::W) = v[u];
+      for (int u = 0; u < B; ++u) {
+        const int it = i0 + u;
+        if (it < G::QL && ((it + 1) * kWave <= FULL || lane < FULL - it * kWave))
+          *reinterpret_cast<V*>(dst + it * kWave * G::W) = v[u];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < B; ++u) {
+        const int it = i0 + u;
+        if (it < G::QL && (unsigned)lane + it * kWave < total) *reinterpret_cast<V*>(dst + it * kWave * G::W) = v[u];
+      }
     }
   }
 }
@@ -184,6 +212,9 @@ __device__ __forceinline__ void qd_rescale(float (&q)[R * D], unsigned flags) {
     const bool live = q[r * D] < INFINITY;
 #pragma unroll
     for (int k = 0; k < D; ++k) q[r * D + k] = live ? q[r * D + k] / div : INFINITY;
+    // a correctly rounded division is ~10 instructions on ~8 registers: one row at a time (interleaved over all the
+    // slots they pushed the run-time configured kernels over their 128 registers, into scratch)
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -375,10 +406,12 @@ __device__ __forceinline__ void qd_ranks_first(const float (&q)[R * D], int (&ra
     const bool l0 = q[b * D] < INFINITY, l1 = p1[0] < INFINITY, l2 = p2[0] < INFINITY, l3 = p3[0] < INFINITY;
 #pragma unroll
     for (int a = 0; a < NB; ++a) {
-      if (a != b) rank[a] += (l0 && key_gt<D, kKeyFirst>(&q[b * D], &q[a * D])) ? 1 : 0;
-      rank[a] += (l1 && key_gt<D, kKeyFirst>(p1, &q[a * D])) ? 1 : 0;
-      rank[a] += (l2 && key_gt<D, kKeyFirst>(p2, &q[a * D])) ? 1 : 0;
-      rank[a] += (l3 && key_gt<D, kKeyFirst>(p3, &q[a * D])) ? 1 : 0;
+      // (every comparison unconditionally, `&` not `&&`: as short circuits they became exec-masked branches whose
+      // counters lived in scratch)
+      if (a != b) rank[a] += (int)(l0 & key_gt<D, kKeyFirst>(&q[b * D], &q[a * D]));
+      rank[a] += (int)(l1 & key_gt<D, kKeyFirst>(p1, &q[a * D]));
+      rank[a] += (int)(l2 & key_gt<D, kKeyFirst>(p2, &q[a * D]));
+      rank[a] += (int)(l3 & key_gt<D, kKeyFirst>(p3, &q[a * D]));
     }
   }
 }
@@ -528,21 +561,32 @@ struct QuadActions {
   RawActions<D> raw;  // kActAny only
 };
 
+// (g0: the wave's first game, wave-uniform; gi: the lane's game inside the slab -- scalar base + 32-bit lane offset)
 template <int D, int ACT>
-__device__ __forceinline__ void quad_actions_issue(QuadActions<D, ACT>& a, const Params& prm, int64_t g, int m, int j) {
+__device__ __forceinline__ void quad_actions_issue(QuadActions<D, ACT>& a, const Params& prm, int64_t g0, unsigned gi,
+                                                   int m, int j) {
   static_assert(D <= kQuad || ACT == kActAny || ACT == kActClassI32AxisI32, "mask broadcast needs dim <= 4");
   if constexpr (ACT == kActAny) {
-    fast_fetch_actions<D>(prm, g, m, a.raw);
+    fast_fetch_actions<D>(prm, g0 + gi, m, a.raw);
   } else {
-    if constexpr (ACT == kActClassI32AxisI32) a.cword = ((const uint32_t*)prm.coords)[g];
-    else a.cword = ((const uint32_t*)prm.coords)[g * D + (j < D ? j : D - 1)];
+    if constexpr (ACT == kActClassI32AxisI32) a.cword = ((const uint32_t*)prm.coords + g0)[gi];
+    else a.cword = ((const uint32_t*)prm.coords + g0 * D)[gi * D + (unsigned)(j < D ? j : D - 1)];
     if constexpr (ACT == kActMaskF32AxisI64) {
-      a.aword = ((const uint32_t*)prm.axis)[2 * g];
-      a.aword_hi = ((const uint32_t*)prm.axis)[2 * g + 1];
+      a.aword = ((const uint32_t*)prm.axis + 2 * g0)[2 * gi];
+      a.aword_hi = ((const uint32_t*)prm.axis + 2 * g0)[2 * gi + 1];
     } else {
-      a.aword = ((const uint32_t*)prm.axis)[g];
+      a.aword = ((const uint32_t*)prm.axis + g0)[gi];
     }
   }
+}
+
+// Both requests are in flight before anything waits: the words pass through one empty asm statement, so no use of
+// either can be scheduled between the two loads.  (Without it the compiler issues the axis request, waits for it AND
+// the slab -- vmcnt counts in order -- and only then asks for the mask word: a second HBM round trip per launch.)
+template <int D, int ACT>
+__device__ __forceinline__ void quad_actions_commit(QuadActions<D, ACT>& a) {
+  if constexpr (ACT == kActMaskF32AxisI64) asm volatile("" : "+v"(a.cword), "+v"(a.aword), "+v"(a.aword_hi));
+  else if constexpr (ACT != kActAny) asm volatile("" : "+v"(a.cword), "+v"(a.aword));
 }
 
 template <int D, int ACT>
@@ -588,7 +632,8 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kBig ? 2 : 4)) void q
   using MaskM = MaskT<M>;
   __shared__ __align__(16) float lds_all[WPB * G::kRegion];
   __shared__ float cbuf_all[WPB * kQuadGames * D];  // slow path only
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+  // the wave index as a scalar: the slab's addresses, the LDS region and the game count stay in SGPRs
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & (kWave - 1);
   float* image = lds_all + wave * G::kRegion;
   float* compact = G::kBig ? image : image + G::kImage;
   const int j = lane & 3, gi = lane >> 2;
@@ -611,9 +656,12 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kBig ? 2 : 4)) void q
   for (int k = 0; k < D; ++k) c[k] = 0.0f;
   QuadActions<D, ACT> actions;
   const bool fetch_actions = (stages & HK_STAGE_SHIFT) && active;
-  if (fetch_actions) quad_actions_issue<D, ACT>(actions, prm, g, M, j);
+  if (fetch_actions) quad_actions_issue<D, ACT>(actions, prm, g0, (unsigned)gi, M, j);
   wait_vmem_all();
-  if (fetch_actions) quad_actions_decode<D, ACT>(actions, prm, c, axis_in);
+  if (fetch_actions) {
+    quad_actions_commit<D, ACT>(actions);
+    quad_actions_decode<D, ACT>(actions, prm, c, axis_in);
+  }
   wave_lds_fence();
 #ifdef HK_QUAD_PROBE  // dev builds only (scripts/build_probe.sh): stop after a phase to see what each one costs
   const int cut = prm.lds_stride;
@@ -641,6 +689,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kBig ? 2 : 4)) void q
   }
   const uint32_t fill_bits = __float_as_uint(fill);
   uint32_t lmask = 0, bad = 0;
+  bool lv[R];  // (the compaction selects on these: compare results stay in scalar registers, no bit tests on lmask)
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     uint32_t hi = __float_as_uint(rows[r * D]), lo = hi;
@@ -652,6 +701,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kBig ? 2 : 4)) void q
     }
     const bool ge = hi < 0x7F800000u;  // every coordinate in [+0, +inf)
     const bool fl = (lo == fill_bits) && (hi == fill_bits);
+    lv[r] = ge && i0 + r < M && active;
     lmask |= (ge && i0 + r < M) ? (1u << r) : 0u;
     bad |= (ge || fl) ? 0u : 1u;
   }
@@ -707,10 +757,14 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kBig ? 2 : 4)) void q
   float* cmine = compact + gi * (G::kBig ? G::kGameStride : M * G::CW);
   {
     int rank = below;
+    // small games: slot of row r = live ? below + (my live rows before r) : (np + i0 - below) + (my dead rows before
+    // r) -- two popcounts with an addend, no chain through the rows
+    const uint32_t dmask = ~lmask;
+    const int dbase = np + i0 - below;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int i = i0 + r;
-      const bool live = (lmask >> r) & 1u;
+      const bool live = G::kBig ? (bool)((lmask >> r) & 1u) : lv[r];
       if constexpr (G::kBig) {
         if (live) {
           float* dst = cmine + rank * G::CW;
@@ -722,7 +776,8 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kBig ? 2 : 4)) void q
           }
         }
       } else {
-        const int slot = live ? rank : np + i - rank;
+        const uint32_t before = (1u << r) - 1u;
+        const int slot = live ? below + __popc(lmask & before) : dbase + __popc(dmask & before);
         if (M % kQuad == 0 || i < M) {  // (rows past M exist only in the last lane's tail when 4 does not divide M)
           float* dst = cmine + slot * G::CW;
           if constexpr (D <= 3) {
@@ -730,16 +785,16 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kBig ? 2 : 4)) void q
             v.x = rows[r * D];
             v.y = D > 1 ? rows[r * D + (D > 1 ? 1 : 0)] : 0.0f;
             v.z = D > 2 ? rows[r * D + (D > 2 ? 2 : 0)] : 0.0f;
-            v.w = __int_as_float(i);
+            v.w = __int_as_float(i * D);  // the tag: where the row lives in the image (floats)
             *reinterpret_cast<vf4*>(dst) = v;
           } else {
 #pragma unroll
             for (int k = 0; k < D; ++k) dst[k] = rows[r * D + k];
-            dst[D] = __int_as_float(i);
+            dst[D] = __int_as_float(i * D);
           }
         }
       }
-      rank += live ? 1 : 0;
+      if constexpr (G::kBig) rank += live ? 1 : 0;
     }
   }
   // slots per lane in use: the wave-uniform maximum of ceil(np / 4) (a downward search: a few ballots)
@@ -748,18 +803,110 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kBig ? 2 : 4)) void q
   while (smax > 1 && !__any(np > kQuad * (smax - 1))) --smax;
   wave_lds_fence();
 
-  // ---- my slots: ranks j, j + 4, ...; slots past the game's live rows are holes.  Small games read all R slots
-  // (no exits, no exec juggling); large ones stop at the wave's smax. ---------------------------------------------------
-  float q[R * D];
-  int orig[G::kBig ? 1 : R];
+  const bool prev_done = np < 2;
+  const int np_before = np;
+  if constexpr (!G::kBig) {
+    // ---- small games: ONE dispatch on the wave's bucket (slots per lane in use), and inside it, straight-line for
+    // that many slots: my slots in (ranks j, j + 4, ...; a slot past the game's live rows is a hole), the transition,
+    // the rows back.  (Round 2 first read all slots, then dispatched the stages, then walked the slots again: three
+    // ladders, and the slots past the bucket materialised as +inf for nobody.) --------------------------------------
+    // list semantics / COMPACT_SORTED (run-time configured kernels only): sorted + compacted output
+    const bool list_sorted = HOT == kHotNone && (stages & HK_STAGE_NEWTON) &&
+                             ((flags & HK_SEM_MASK) == HK_SEM_LIST || (flags & HK_FLAG_COMPACT_SORTED));
+    // ... or the observation features: rows in descending key order (hk_get_features / hk_get_features_torch)
+    const bool sorted = list_sorted || (HOT == kHotNone && (stages & kStageFeatureSorts));
+#ifdef HK_QUAD_PROBE
+    float probe_acc = 0.0f;
+#endif
+    unrolled_while<1, R + 1>([&](auto nbc) {
+      constexpr int NB = decltype(nbc)::value;
+      if (NB < R && smax > NB) return true;
+      float q[R * D];
+      int orig[R], rank[R];
 #pragma unroll
-  for (int e = 0; e < R * D; ++e) q[e] = INFINITY;
-  unrolled_while<0, R>([&](auto sc) {
-    constexpr int s = decltype(sc)::value;
-    if (s >= smax && (G::kBig || s >= 2)) return false;  // (small games: the first two slots without a branch)
-    const bool has = kQuad * s + j < np;
-    const float* src = cmine + (kQuad * s + j < M ? kQuad * s + j : 0) * G::CW;
-    if constexpr (G::kBig) {
+      for (int s = 0; s < NB; ++s) {
+        const bool has = kQuad * s + j < np;
+        const float* src = cmine + (kQuad * s + j < M ? kQuad * s + j : 0) * G::CW;
+        if constexpr (D <= 3) {
+          const vf4 v = *reinterpret_cast<const vf4*>(src);
+          q[s * D] = has ? v.x : INFINITY;
+          if (D > 1) q[s * D + (D > 1 ? 1 : 0)] = has ? v.y : INFINITY;
+          if (D > 2) q[s * D + (D > 2 ? 2 : 0)] = has ? v.z : INFINITY;
+          orig[s] = __float_as_int(v.w);
+        } else {
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            const float v = src[k];
+            q[s * D + k] = has ? v : INFINITY;
+          }
+          orig[s] = __float_as_int(src[D]);
+        }
+      }
+#ifdef HK_QUAD_PROBE
+      if (cut == 3 || cut == 4) {
+        if (cut == 4) qd_stages<M, G::CW, R, D, NB>(q, c, axis_in, np, j, flags, stages, cmine, M, list_sorted, rank);
+#pragma unroll
+        for (int e = 0; e < NB * D; ++e) probe_acc += (q[e] < INFINITY) ? q[e] : 0.0f;
+        return false;
+      }
+#endif
+      np = qd_stages<M, G::CW, R, D, NB>(q, c, axis_in, np, j, flags, stages, cmine, M, list_sorted, rank);
+      if (sorted) {
+        // list semantics: padding everywhere (the quads fill the wave's image in 16-B pieces), then every survivor at
+        // its rank
+#pragma unroll
+        for (int it = 0; it < G::QL; ++it) {
+          const int qq = lane + it * kWave;
+          if (qq < kQuadGames * G::Q) {
+            if constexpr (G::W == 4) *reinterpret_cast<vf4*>(image + qq * 4) = vf4{pad, pad, pad, pad};
+            else if constexpr (G::W == 2) *reinterpret_cast<vf2*>(image + qq * 2) = vf2{pad, pad};
+            else image[qq] = pad;
+          }
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+          if (q[s * D] < INFINITY) {
+            float* dst = mine + rank[s] * D;
+#pragma unroll
+            for (int k = 0; k < D; ++k) dst[k] = q[s * D + k];
+          }
+        }
+      } else {
+        // in place: the row of every slot in use goes back to its own place in the image -- new coordinates if it
+        // survived, padding if it was removed; the dead rows that sit in the slots past the live ones are padding
+        // already and are rewritten as such (unconditional writes)
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+          if (M % kQuad == 0 || kQuad * s + j < M) {
+            const bool removed = !(q[s * D] < INFINITY);
+            float* dst = mine + orig[s];
+#pragma unroll
+            for (int k = 0; k < D; ++k) dst[k] = removed ? pad : q[s * D + k];
+          }
+        }
+      }
+      return false;
+    });
+#ifdef HK_QUAD_PROBE
+    if (cut == 3 || cut == 4) {
+      if (leader && prm.reward_out) prm.reward_out[g] = probe_acc;
+      quad_slab_store<M, D>(image, (float*)prm.out + g0 * G::N, ngames, lane);
+      return;
+    }
+#endif
+  }
+
+  // ---- large games: my slots (ranks j, j + 4, ... up to the wave's smax; slots past the game's live rows are holes)
+  float q[G::kBig ? R * D : 1];
+  if constexpr (G::kBig) {
+#pragma unroll
+    for (int e = 0; e < R * D; ++e) q[e] = INFINITY;
+    unrolled_while<0, R>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if (s >= smax) return false;
+      const bool has = kQuad * s + j < np;
+      const float* src = cmine + (kQuad * s + j < M ? kQuad * s + j : 0) * G::CW;
       if constexpr (D == 4) {
         const vf4 v = *reinterpret_cast<const vf4*>(src);
         q[s * D] = has ? v.x : INFINITY;
@@ -773,102 +920,40 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kBig ? 2 : 4)) void q
           q[s * D + k] = has ? v : INFINITY;
         }
       }
-    } else if constexpr (D <= 3) {
-      const vf4 v = *reinterpret_cast<const vf4*>(src);
-      q[s * D] = has ? v.x : INFINITY;
-      if (D > 1) q[s * D + (D > 1 ? 1 : 0)] = has ? v.y : INFINITY;
-      if (D > 2) q[s * D + (D > 2 ? 2 : 0)] = has ? v.z : INFINITY;
-      orig[s] = __float_as_int(v.w);
-    } else {
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        const float v = src[k];
-        q[s * D + k] = has ? v : INFINITY;
-      }
-      orig[s] = __float_as_int(src[D]);
-    }
-    return true;
-  });
-
-#ifdef HK_QUAD_PROBE
-  if (cut == 3) {
-    float acc = 0.0f;
-#pragma unroll
-    for (int e = 0; e < R * D; ++e) acc += (q[e] < INFINITY) ? q[e] : 0.0f;
-    if (leader && prm.reward_out) prm.reward_out[g] = acc;
-    quad_slab_store<M, D>(image, (float*)prm.out + g0 * G::N, ngames, lane);
-    return;
-  }
-#endif
-  // ---- the transition -------------------------------------------------------------------------------------------------
-  const bool prev_done = np < 2;
-  const int np_before = np;
-  // list semantics / COMPACT_SORTED (small games, run-time configured kernels only): sorted + compacted output
-  const bool list_sorted = !G::kBig && HOT == kHotNone && (stages & HK_STAGE_NEWTON) &&
-                           ((flags & HK_SEM_MASK) == HK_SEM_LIST || (flags & HK_FLAG_COMPACT_SORTED));
-  // ... or the observation features: rows in descending key order (hk_get_features / hk_get_features_torch)
-  const bool sorted = list_sorted || (!G::kBig && HOT == kHotNone && (stages & kStageFeatureSorts));
-  int rank[R];
-  np = QuadStagesFor<M, D, 1>::run(q, smax, c, axis_in, np, j, flags, stages, cmine, list_sorted, rank);
-  const bool done = np < 2;
-  if (leader) {
-    if (prm.done_out) prm.done_out[g] = done;
-    if (prm.prev_done_out) prm.prev_done_out[g] = prev_done;
-    if (prm.reward_out) prm.reward_out[g] = prm.reward_sign * (float)(done && !prev_done);
-    if (prm.num_points_out) prm.num_points_out[g] = np;
-  }
-
-#ifdef HK_QUAD_PROBE
-  if (cut == 4) {
-    float acc = 0.0f;
-#pragma unroll
-    for (int e = 0; e < R * D; ++e) acc += (q[e] < INFINITY) ? q[e] : 0.0f;
-    if (leader && prm.reward_out) prm.reward_out[g] = acc;
-    quad_slab_store<M, D>(image, (float*)prm.out + g0 * G::N, ngames, lane);
-    return;
-  }
-#endif
-  if (!G::kBig && sorted) {
-    // ---- list semantics: padding everywhere (the quads fill the wave's image in 16-B pieces), then every survivor at
-    // its rank -----------------------------------------------------------------------------------------------------
-    if constexpr (!G::kBig) {
-#pragma unroll
-      for (int it = 0; it < G::QL; ++it) {
-        const int qq = lane + it * kWave;
-        if (qq < kQuadGames * G::Q) {
-          if constexpr (G::W == 4) *reinterpret_cast<vf4*>(image + qq * 4) = vf4{pad, pad, pad, pad};
-          else if constexpr (G::W == 2) *reinterpret_cast<vf2*>(image + qq * 2) = vf2{pad, pad};
-          else image[qq] = pad;
-        }
-      }
-      wave_lds_fence();
-      unrolled_while<0, R>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        if (s >= smax) return false;
-        if (q[s * D] < INFINITY) {
-          float* dst = mine + rank[s] * D;
-#pragma unroll
-          for (int k = 0; k < D; ++k) dst[k] = q[s * D + k];
-        }
-        return true;
-      });
-    }
-  } else if constexpr (!G::kBig) {
-    // ---- in place: the row of every slot in use goes back to its own place in the image -- new coordinates if it
-    // survived, padding if it was removed; the dead rows that sit in the slots past the live ones are padding already
-    // and are rewritten as such (unconditional writes) ----------------------------------------------------------------
-    unrolled_while<0, R>([&](auto sc) {
-      constexpr int s = decltype(sc)::value;
-      if (s >= smax) return false;
-      if (M % kQuad == 0 || kQuad * s + j < M) {
-        const bool removed = !(q[s * D] < INFINITY);
-        float* dst = mine + orig[s] * D;
-#pragma unroll
-        for (int k = 0; k < D; ++k) dst[k] = removed ? pad : q[s * D + k];
-      }
       return true;
     });
-  } else {
+#ifdef HK_QUAD_PROBE
+    if (cut == 3) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int e = 0; e < R * D; ++e) acc += (q[e] < INFINITY) ? q[e] : 0.0f;
+      if (leader && prm.reward_out) prm.reward_out[g] = acc;
+      quad_slab_store<M, D>(image, (float*)prm.out + g0 * G::N, ngames, lane);
+      return;
+    }
+#endif
+    int rank[R];
+    np = QuadStagesFor<M, D, 1>::run(q, smax, c, axis_in, np, j, flags, stages, cmine, false, rank);
+  }
+  const bool done = np < 2;
+  if (leader) {  // (scalar base + the lane's game index: no 64-bit address arithmetic per output)
+    const unsigned ug = (unsigned)gi;
+    if (prm.done_out) (prm.done_out + g0)[ug] = done;
+    if (prm.prev_done_out) (prm.prev_done_out + g0)[ug] = prev_done;
+    if (prm.reward_out) (prm.reward_out + g0)[ug] = prm.reward_sign * (float)(done && !prev_done);
+    if (prm.num_points_out) (prm.num_points_out + g0)[ug] = np;
+  }
+  if constexpr (G::kBig) {
+#ifdef HK_QUAD_PROBE
+    if (cut == 4) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int e = 0; e < R * D; ++e) acc += (q[e] < INFINITY) ? q[e] : 0.0f;
+      if (leader && prm.reward_out) prm.reward_out[g] = acc;
+      quad_slab_store<M, D>(image, (float*)prm.out + g0 * G::N, ngames, lane);
+      return;
+    }
+#endif
     // ---- large games: every slot in use returns its row (padding if it was removed) to its compact slot; the lane
     // that OWNS row i (it scanned it, it knows its rank) picks it up there and rebuilds its rows of the image: a dead
     // row is padding, as it was.  All reads of the compact image precede the first write of the slab image in the
