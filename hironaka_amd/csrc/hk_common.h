@@ -82,6 +82,7 @@ struct Params {
   // row length of count_ws: the same for every kernel variant that may serve a geometry (>= any of their
   // grids), so that deferred counts of different launches meet in one workspace
   uint32_t count_stride;
+  float pad_f32;  // (float)pad, filled in by launchers whose kernels would otherwise convert per wave
 };
 
 // hipGetLastError() is sticky per host thread and other users of the runtime in this process

@@ -646,7 +646,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kBig ? 2 : 4)) void q
   const int64_t g = g0 + gi;
   quad_slab_load<M, D>(in0 + g0 * G::N, image, ngames, lane);
   float* mine = image + gi * G::N;
-  const float pad = (float)prm.pad;
+  const float pad = prm.pad_f32;
   const unsigned flags = (HOT == kHotJax) ? (unsigned)HK_SEM_JAX : prm.flags;
   const unsigned stages = HOT ? (unsigned)(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON) : prm.stages;
   const float fill = ((flags & HK_SEM_MASK) == HK_SEM_JAX) ? -1.0f : pad;
@@ -777,7 +777,9 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kBig ? 2 : 4)) void q
         }
       } else {
         const uint32_t before = (1u << r) - 1u;
-        const int slot = live ? below + __popc(lmask & before) : dbase + __popc(dmask & before);
+        const uint32_t msel = live ? lmask : dmask;  // (select the operands, not the results: one popcount per row)
+        const int bsel = live ? below : dbase;
+        const int slot = bsel + __popc(msel & before);
         if (M % kQuad == 0 || i < M) {  // (rows past M exist only in the last lane's tail when 4 does not divide M)
           float* dst = cmine + slot * G::CW;
           if constexpr (D <= 3) {
@@ -823,10 +825,14 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kBig ? 2 : 4)) void q
       if (NB < R && smax > NB) return true;
       float q[R * D];
       int orig[R], rank[R];
+      const int npj = np - j;
+      const float* cj = cmine + j * G::CW;
 #pragma unroll
       for (int s = 0; s < NB; ++s) {
-        const bool has = kQuad * s + j < np;
-        const float* src = cmine + (kQuad * s + j < M ? kQuad * s + j : 0) * G::CW;
+        // (slot s of lane j is rank 4 s + j: one lane base, the slot in the read's immediate; np - j against a constant)
+        const bool has = kQuad * s < npj;
+        const float* src = (kQuad * s + kQuad <= M) ? cj + kQuad * s * G::CW
+                                                    : cmine + (kQuad * s + j < M ? kQuad * s + j : 0) * G::CW;
         if constexpr (D <= 3) {
           const vf4 v = *reinterpret_cast<const vf4*>(src);
           q[s * D] = has ? v.x : INFINITY;
@@ -1041,6 +1047,7 @@ int launch_quad_w(Params prm, hipStream_t stream) {
   const int64_t waves = ((int64_t)prm.batch + kQuadGames - 1) / kQuadGames;
   const unsigned grid = (unsigned)((waves + WPB - 1) / WPB);
   prm.games_per_block = kQuadGames * WPB;
+  prm.pad_f32 = (float)prm.pad;
   launch_prepare();
   const bool hot = prm.flags == HK_SEM_JAX && prm.stages == (HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON);
   const int act = quad_act_of(prm);
