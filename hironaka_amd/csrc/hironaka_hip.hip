@@ -478,6 +478,47 @@ int hk_search_policy(const hk_search_tree* tree, const float* root_gumbel, const
   return launch_search_policy(s, root_gumbel, root_invalid, action_out, action_weights_out, (hipStream_t)stream);
 }
 
+static int expand_shape_ok(int batch, int num_nodes, int max_points, int dim) {
+  if (batch < 0 || num_nodes < 1 || max_points < 1 || dim < 2 || dim > kMaxDim) return HK_ERR_SHAPE;
+  if ((int64_t)max_points * dim > (1 << 20) || (int64_t)batch * num_nodes > (int64_t)1 << 40) return HK_ERR_SHAPE;
+  return HK_OK;
+}
+
+int hk_search_expand_gather(const void* embeddings, const void* features, const int32_t* parent,
+                            const int32_t* action, void* obs_out, void* agent_feat_out, int batch,
+                            int num_nodes, int max_points, int dim, void* stream) {
+  const int st = expand_shape_ok(batch, num_nodes, max_points, dim);
+  if (st != HK_OK) return st;
+  if (batch == 0) return HK_OK;
+  if (!embeddings || !features || !parent || !action || !obs_out || !agent_feat_out) return HK_ERR_NULL;
+  if (!aligned(embeddings, 4) || !aligned(features, 4) || !aligned(parent, 4) || !aligned(action, 4) ||
+      !aligned(obs_out, 4) || !aligned(agent_feat_out, 4))
+    return HK_ERR_ALIGN;
+  return launch_expand_gather((const float*)embeddings, (const float*)features, parent, action, (float*)obs_out,
+                              (float*)agent_feat_out, batch, num_nodes, max_points * dim, dim, (hipStream_t)stream);
+}
+
+int hk_search_masked_argmax(const void* logits, const int32_t* action, int32_t* axis_out, int batch, int dim,
+                            void* stream) {
+  if (batch < 0 || dim < 2 || dim > kMaxDim) return HK_ERR_SHAPE;
+  if (batch == 0) return HK_OK;
+  if (!logits || !action || !axis_out) return HK_ERR_NULL;
+  if (!aligned(logits, 4) || !aligned(action, 4) || !aligned(axis_out, 4)) return HK_ERR_ALIGN;
+  return launch_masked_argmax((const float*)logits, action, axis_out, batch, dim, (hipStream_t)stream);
+}
+
+int hk_search_expand_scatter(const void* obs, const void* feat, const int32_t* node, void* embeddings,
+                             void* features, int batch, int num_nodes, int max_points, int dim, void* stream) {
+  const int st = expand_shape_ok(batch, num_nodes, max_points, dim);
+  if (st != HK_OK) return st;
+  if (batch == 0) return HK_OK;
+  if (!obs || !feat || !node || !embeddings || !features) return HK_ERR_NULL;
+  if (!aligned(obs, 4) || !aligned(feat, 4) || !aligned(node, 4) || !aligned(embeddings, 4) || !aligned(features, 4))
+    return HK_ERR_ALIGN;
+  return launch_expand_scatter((const float*)obs, (const float*)feat, node, (float*)embeddings, (float*)features,
+                               batch, num_nodes, max_points * dim, (hipStream_t)stream);
+}
+
 int hk_zeillinger(const void* points, int64_t stride, int32_t* class_out, int batch,
                   int max_points, int dim, int dtype, uint32_t flags, void* stream) {
   int st = check_spec(batch, max_points, dim, dtype);

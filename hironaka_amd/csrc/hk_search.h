@@ -303,4 +303,96 @@ inline int launch_search_policy(const SearchTree& t, const float* gumbel, const 
   return launch_status();
 }
 
+// ---- expansion glue of a host-role tree (hironaka/jax/recurrent_fn.py:84-104 between the search's select and its
+// backward pass).  The tree keeps, per node, the points (embeddings [B, N, E], E = max_points * dim) and their
+// observation features (features [B, N, E]: what hk_get_features makes of the points -- computed ONCE, when the node
+// is created, for the host network; the agent network of a later expansion reads the same rows).  Three small
+// kernels replace the ~9 tensor-library launches of an expansion (gather, decode, two concatenations, the feature
+// sort of the strided agent observation, mask fill / compare / where / argmax, index_put). ----------------------------
+
+// obs_out [B, E] = embeddings[b, parent[b]];  agent_feat_out [B, E + d] = features[b, parent[b]] ++ the 0/1 subset of
+// the host's class id (host_action_preprocess: class -> mask, out-of-range ids clamped like hk_decode_host_class)
+__global__ void expand_gather_kernel(const float* emb, const float* feat, const int32_t* parent, const int32_t* action,
+                                     float* obs_out, float* agent_feat_out, int batch, int nodes, int E, int d) {
+  const int per = 2 * E + d;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)batch * per) return;
+  const int g = (int)(idx / per), e = (int)(idx % per);
+  int p = parent[g];
+  p = p < 0 ? 0 : (p >= nodes ? nodes - 1 : p);
+  const int64_t row = ((int64_t)g * nodes + p) * E;
+  if (e < E) {
+    obs_out[(int64_t)g * E + e] = emb[row + e];
+  } else if (e < 2 * E) {
+    agent_feat_out[(int64_t)g * (E + d) + (e - E)] = feat[row + (e - E)];
+  } else {
+    const int k = e - 2 * E;
+    const int ncls = (int)((1ll << d) - d - 1);
+    int c = action[g];
+    c = c < 0 ? 0 : (c >= ncls ? ncls - 1 : c);
+    agent_feat_out[(int64_t)g * (E + d) + E + k] = (float)((decode_class(c, d) >> k) & 1u);
+  }
+}
+
+// the agent's answer: argmax of its logits over the coordinates of the host's subset (jax/util.py:287-327: logits
+// outside the subset count as -inf; the first maximum wins; a NaN beats every number, as in the tensor libraries)
+__global__ void masked_argmax_kernel(const float* logits, const int32_t* action, int32_t* axis_out, int batch, int d) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= batch) return;
+  const int ncls = (int)((1ll << d) - d - 1);
+  int c = action[g];
+  c = c < 0 ? 0 : (c >= ncls ? ncls - 1 : c);
+  const uint32_t mask = decode_class(c, d);
+  int best = 0;
+  float bv = ((mask >> 0) & 1u) ? logits[(int64_t)g * d] : -INFINITY;
+  for (int k = 1; k < d; ++k) {
+    const float v = ((mask >> k) & 1u) ? logits[(int64_t)g * d + k] : -INFINITY;
+    if ((v > bv) || (v != v && bv == bv)) {
+      best = k;
+      bv = v;
+    }
+  }
+  axis_out[g] = best;
+}
+
+// embeddings[b, node[b]] = obs[b];  features[b, node[b]] = feat[b]
+__global__ void expand_scatter_kernel(const float* obs, const float* feat_in, const int32_t* node, float* emb,
+                                      float* feat, int batch, int nodes, int E) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)batch * 2 * E) return;
+  const int g = (int)(idx / (2 * E)), e = (int)(idx % (2 * E));
+  const int n = node[g];
+  if (n < 0 || n >= nodes) return;
+  const int64_t row = ((int64_t)g * nodes + n) * E;
+  if (e < E) emb[row + e] = obs[(int64_t)g * E + e];
+  else feat[row + (e - E)] = feat_in[(int64_t)g * E + (e - E)];
+}
+
+inline int launch_expand_gather(const float* emb, const float* feat, const int32_t* parent, const int32_t* action,
+                                float* obs_out, float* agent_feat_out, int batch, int nodes, int E, int d,
+                                hipStream_t stream) {
+  launch_prepare();
+  const int64_t total = (int64_t)batch * (2 * E + d);
+  hipLaunchKernelGGL(expand_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, emb, feat,
+                     parent, action, obs_out, agent_feat_out, batch, nodes, E, d);
+  return launch_status();
+}
+
+inline int launch_masked_argmax(const float* logits, const int32_t* action, int32_t* axis_out, int batch, int d,
+                                hipStream_t stream) {
+  launch_prepare();
+  hipLaunchKernelGGL(masked_argmax_kernel, dim3((batch + 255) / 256), dim3(256), 0, stream, logits, action, axis_out,
+                     batch, d);
+  return launch_status();
+}
+
+inline int launch_expand_scatter(const float* obs, const float* feat_in, const int32_t* node, float* emb, float* feat,
+                                 int batch, int nodes, int E, hipStream_t stream) {
+  launch_prepare();
+  const int64_t total = (int64_t)batch * 2 * E;
+  hipLaunchKernelGGL(expand_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, obs, feat_in,
+                     node, emb, feat, batch, nodes, E);
+  return launch_status();
+}
+
 }  // namespace hk

@@ -26,9 +26,81 @@ class RecurrentFnOutput(NamedTuple):
     value: torch.Tensor
 
 
+class HostExpander:
+    """One expansion of a HOST-role tree as fused device work (recurrent_fn.py:84-104 around the two networks):
+
+        hk_search_expand_gather  (parent points + parent features ++ subset of the host's class id)
+        -> agent network -> hk_search_masked_argmax -> hk_step (class ids, int32 axis) -> hk_get_features
+        -> hk_search_expand_scatter (points and features of the new node) -> host network
+
+    instead of gather / decode / concat / feature sort of the strided agent observation / concat / mask fill /
+    compare / where / argmax / step / feature sort / index_put.  It needs the two networks as
+    ``model(features, params) -> (logits, value)`` behind the STANDARD feature functions (functional.get_feature_fn:
+    the observation features of a node are computed once, when the node is created, and kept in a second table
+    next to the embeddings), so it is what ``HipTrainer`` builds for its own policies; arbitrary callables keep
+    the generic path below.  Results are identical to the generic path (tests/test_gpu_trainer.py)."""
+
+    def __init__(self, host_model: Callable, agent_model: Callable, spec: Tuple[int, int], discount: float,
+                 scale_observation: bool, reposition: bool, rescale_points: bool = False, reward_sign: float = 1.0):
+        from . import ops
+        self.host_model, self.agent_model = host_model, agent_model
+        self.m, self.d = spec
+        self.discount = discount
+        self.scale_observation = scale_observation
+        self.reward_sign = reward_sign
+        self.stages = ops.make_stages(shift=True, reposition=reposition, newton=True, rescale=rescale_points)
+
+    def accepts(self, root_embedding: torch.Tensor) -> bool:
+        return (root_embedding.is_cuda and root_embedding.dtype == torch.float32 and root_embedding.dim() == 2
+                and root_embedding.shape[1] == self.m * self.d)
+
+    def begin(self, tree, root_embedding: torch.Tensor):
+        """per search: the feature table (root row filled) and the scratch arrays of an expansion"""
+        from . import ops
+        b, n, e = tree.embeddings.shape
+        dev = tree.embeddings.device
+        features = torch.zeros((b, n, e), dtype=torch.float32, device=dev)
+        features[:, 0] = ops.get_features(root_embedding.contiguous(), self.scale_observation, spec=(self.m, self.d))
+        return {"features": features,
+                "obs": torch.empty((b, e), dtype=torch.float32, device=dev),
+                "agent_feat": torch.empty((b, e + self.d), dtype=torch.float32, device=dev),
+                "axis": torch.empty(b, dtype=torch.int32, device=dev),
+                "discount": torch.full((b,), self.discount, dtype=torch.float32, device=dev)}
+
+    def expand(self, params, key, tree, state, parent: torch.Tensor, action: torch.Tensor, node: torch.Tensor):
+        import ctypes as C
+
+        from . import ops
+        from ._lib import check, lib
+        (host_params, *_), (agent_params, *_) = params
+        b, n, e = tree.embeddings.shape
+        m, d = self.m, self.d
+        L = lib()
+        stream = C.c_void_p(torch.cuda.current_stream(tree.embeddings.device).cuda_stream)
+        obs, agent_feat, axis, features = state["obs"], state["agent_feat"], state["axis"], state["features"]
+        check(L.hk_search_expand_gather(tree.embeddings.data_ptr(), features.data_ptr(), parent.data_ptr(),
+                                        action.data_ptr(), obs.data_ptr(), agent_feat.data_ptr(), b, n, m, d, stream),
+              "hk_search_expand_gather")
+        logits, _ = self.agent_model(agent_feat, agent_params)
+        logits = logits.to(torch.float32).contiguous()
+        check(L.hk_search_masked_argmax(logits.data_ptr(), action.data_ptr(), axis.data_ptr(), b, d, stream),
+              "hk_search_masked_argmax")
+        res = ops.step(obs, action, axis, stages=self.stages, spec=(m, d), want=("done", "prev_done", "reward"),
+                       reward_sign=self.reward_sign)
+        nxt = res["points"].reshape(b, e)
+        host_feat = ops.get_features(nxt, self.scale_observation, spec=(m, d))
+        check(L.hk_search_expand_scatter(nxt.data_ptr(), host_feat.data_ptr(), node.data_ptr(),
+                                         tree.embeddings.data_ptr(), features.data_ptr(), b, n, m, d, stream),
+              "hk_search_expand_scatter")
+        prior, value = self.host_model(host_feat, host_params)
+        return RecurrentFnOutput(reward=res["reward"], discount=state["discount"], prior_logits=prior,
+                                 value=value.reshape(b))
+
+
 def get_recurrent_fn_for_role(role: str, role_fn: Callable, opponent_action_fn: Callable, reward_fn: Callable,
                               spec: Tuple[int, int], discount: float = 0.99, dtype=torch.float32,
-                              rescale_points: bool = False, reposition: bool = False) -> Callable:
+                              rescale_points: bool = False, reposition: bool = False,
+                              expander: "HostExpander | None" = None) -> Callable:
     """recurrent_fn.py:17-123.
     role_fn(observations, *args, key=...) -> (policy_prior, value_prior) of the player under evaluation;
     opponent_action_fn(observations, *args, key=...) -> one-hot actions of the fixed opponent;
@@ -86,6 +158,8 @@ def get_recurrent_fn_for_role(role: str, role_fn: Callable, opponent_action_fn: 
                                 value=value_prior)
         return out, next_observations
 
+    # (not in the reference) a search loop that knows about it runs the expansion through the fused operators
+    recurrent_fn.expander = expander if role == "host" else None
     return recurrent_fn
 
 

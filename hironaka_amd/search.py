@@ -151,16 +151,25 @@ def _run_search(params, rng_key, root: RootFnOutput, gumbel: torch.Tensor, inval
     rows = torch.arange(b, device=dev)
     inv_ptr = None if invalid_u8 is None else invalid_u8.data_ptr()
     L = lib()
+    # a recurrent_fn built by recurrent_fn.get_recurrent_fn_for_role may offer its expansion as fused operators
+    # (recurrent_fn.HostExpander: gather / opponent argmax / step / features / scatter without the tensor-library glue)
+    expander = getattr(recurrent_fn, "expander", None)
+    if expander is not None and not expander.accepts(root.embedding):
+        expander = None
     with torch.cuda.device(dev):
+        expand_state = expander.begin(tree, root.embedding) if expander is not None else None
         for sim in range(num_simulations):
             check(L.hk_search_select(C.byref(desc), gumbel.data_ptr(), inv_ptr, table.data_ptr(),
                                      max_num_considered_actions, num_simulations, max_depth, sim + 1,
                                      parent.data_ptr(), action.data_ptr(), node.data_ptr(), _stream(gumbel)),
                   "hk_search_select")
-            embedding = tree.embeddings[rows, parent]  # int32 indices are fine
-            # (actions travel as int32, as in mctx; the HIP operators take them as they are)
-            step, next_embedding = recurrent_fn(params, simulation_key(rng_key, sim), action, embedding)
-            tree.embeddings[rows, node] = next_embedding.to(tree.embeddings.dtype)
+            if expander is not None:
+                step = expander.expand(params, simulation_key(rng_key, sim), tree, expand_state, parent, action, node)
+            else:
+                embedding = tree.embeddings[rows, parent]  # int32 indices are fine
+                # (actions travel as int32, as in mctx; the HIP operators take them as they are)
+                step, next_embedding = recurrent_fn(params, simulation_key(rng_key, sim), action, embedding)
+                tree.embeddings[rows, node] = next_embedding.to(tree.embeddings.dtype)
             logits = step.prior_logits.to(torch.float32).contiguous()
             value = step.value.to(torch.float32).contiguous()
             reward = step.reward.to(torch.float32).contiguous()

@@ -27,12 +27,14 @@ def get_evaluation_loop(role: str, policy_fn: Callable, opponent_fn: Callable, r
                         spec: Tuple[int, int], num_evaluations: int, max_depth: int,
                         max_num_considered_actions: int, discount: float, rescale_points: bool, reposition: bool,
                         role_agnostic: Optional[bool] = None, gumbel_scale: Optional[float] = 0.3,
-                        dtype=torch.float32, use_graph: bool = False) -> Callable:
+                        dtype=torch.float32, use_graph: bool = False, expander=None) -> Callable:
     """simulation_fn.py:16-122.  policy_fn(observations, *args, key=) -> (policy_prior, value_prior);
     opponent_fn(observations, *args, key=) -> one-hot actions; reward_fn(dones, prev_dones) -> rewards.
     use_graph (not in the reference): capture the search of each distinct batch shape into a hipGraph
     (search.CapturedSearch: its requirements apply -- role-specific trees only, callables without host
-    synchronisation, randomness from torch's default generator, same argument objects on every call)."""
+    synchronisation, randomness from torch's default generator, same argument objects on every call).
+    expander (not in the reference): a recurrent_fn.HostExpander -- the expansions of a host-role tree through the
+    fused operators."""
     if role_agnostic:
         policy_fn_on_root = get_dynamic_policy_fn(spec, policy_fn, opponent_fn)
         recurrent_fn = get_unified_recurrent_fn(policy_fn, opponent_fn, reward_fn, spec, discount=discount,
@@ -43,7 +45,8 @@ def get_evaluation_loop(role: str, policy_fn: Callable, opponent_fn: Callable, r
             return policy_fn(state, *params, *args, **kwargs)
 
         recurrent_fn = get_recurrent_fn_for_role(role, policy_fn, opponent_fn, reward_fn, spec, discount=discount,
-                                                 dtype=dtype, rescale_points=rescale_points, reposition=reposition)
+                                                 dtype=dtype, rescale_points=rescale_points, reposition=reposition,
+                                                 expander=expander)
 
     if use_graph and role_agnostic:
         raise ValueError("the role-agnostic tree decides host/agent on the host per call: not capturable")

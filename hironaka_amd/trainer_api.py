@@ -37,6 +37,7 @@ from .host_action_preprocess import get_batch_decode_from_one_hot
 from .players import (all_coord_host_fn, choose_first_agent_fn, choose_last_agent_fn, get_host_with_flattened_obs,
                       get_name, random_agent_fn, random_host_fn, zeillinger_fn)
 from .rollout import compute_rho as _compute_rho
+from .recurrent_fn import HostExpander
 from .rollout import rollout_postprocess as _rollout_postprocess
 from .simulation_fn import get_evaluation_loop, get_simulation
 
@@ -96,7 +97,8 @@ class HipTrainer:
     def __init__(self, key: int, config: Union[dict, str], dtype=torch.float32,
                  host_net: Optional[Callable] = None, agent_net: Optional[Callable] = None,
                  host_params: Any = None, agent_params: Any = None,
-                 host_feature_fn=None, agent_feature_fn=None, device=None, use_graph: bool = False):
+                 host_feature_fn=None, agent_feature_fn=None, device=None, use_graph: bool = False,
+                 fused_expand: bool = True):
         if isinstance(config, str):
             import yaml
             with open(config, "r") as stream:
@@ -115,6 +117,9 @@ class HipTrainer:
         if self.device.type != "cuda":
             raise TypeError("HipTrainer lives on a HIP device (there is no CPU path)")
         self.use_graph = use_graph
+        # host-role trees of the trainer's own policies expand through the fused operators (recurrent_fn.HostExpander)
+        # -- possible while the standard feature functions sit in front of the networks
+        self.fused_expand = bool(fused_expand) and host_feature_fn is None and agent_feature_fn is None
         self.key = int(key)
         spec = (self.max_num_points, self.dimension)
         self.host_feature_fn = host_feature_fn if host_feature_fn is not None else \
@@ -185,6 +190,7 @@ class HipTrainer:
         simulation_config = {"eval_batch_size": self.eval_batch_size, "max_num_points": self.max_num_points,
                              "dimension": self.dimension, "max_length_game": self.max_length_game, "dtype": self.dtype}
         mcts_opponent = opp_policy_fn is not None
+        own_policies = policy_fn is None and opp_policy_fn is None
         policy_fn = getattr(self, f"{role}_policy_fn") if policy_fn is None else policy_fn
         opp_policy_fn = getattr(self, f"{opponent}_policy_fn") if opp_policy_fn is None else opp_policy_fn
         eval_loop_config = {
@@ -197,13 +203,18 @@ class HipTrainer:
             # one hipGraph per search: only where nothing inside synchronises with the host (an opponent that is
             # itself a search does)
             "use_graph": self.use_graph and not mcts_opponent,
+            "expander": (HostExpander(self.host_model, self.agent_model, spec, self.discount, self.scale_observation,
+                                      self.reposition, rescale_points=False,
+                                      reward_sign=getattr(self.host_reward_fn, "hk_reward_sign", 1.0))
+                         if role == "host" and own_policies and self.fused_expand and self.dtype == torch.float32
+                         else None),
         }
         eval_loop_with_gumbel = get_evaluation_loop(gumbel_scale=self.gumbel_scale, **eval_loop_config)
         eval_loop = get_evaluation_loop(gumbel_scale=0.0, **eval_loop_config)
         eval_loop_as_opp = get_evaluation_loop(
             gumbel_scale=0.0, **{**eval_loop_config, "num_evaluations": self.num_evaluations_as_opponent})
         unified_eval_loop_config = {
-            **eval_loop_config, "role": "host", "use_graph": False,
+            **eval_loop_config, "role": "host", "use_graph": False, "expander": None,
             "policy_fn": get_host_with_flattened_obs(spec, self._host_policy_on_points, truncate_input=True),
             "opponent_fn": self.agent_policy_fn,
             "reward_fn": self.agent_reward_fn,  # agent: the off-by-one-step convention of the unified tree

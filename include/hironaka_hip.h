@@ -269,6 +269,25 @@ int hk_search_backup(const hk_search_tree* tree, const int32_t* parent, const in
 int hk_search_policy(const hk_search_tree* tree, const float* root_gumbel, const uint8_t* root_invalid,
                      int32_t* action_out, float* action_weights_out, void* stream);
 
+/* ---- expansion glue of a HOST-role tree (hironaka/jax/recurrent_fn.py:84-104: host class id -> subset, the
+ * agent observation, the opponent's masked argmax, the step, the new embedding) ---------------------------
+ * The caller keeps two tables per tree: embeddings [B, N, E] (the points of every node, E = max_points*dim,
+ * float32) and features [B, N, E] (hk_get_features of those points, written once when a node is created).
+ * One expansion = hk_search_expand_gather -> agent network on agent_feat_out -> hk_search_masked_argmax ->
+ * hk_step (class-id coords, int32 axis) -> hk_get_features -> hk_search_expand_scatter -> host network. */
+/* obs_out [B, E] = embeddings[b, parent[b]]; agent_feat_out [B, E + dim] = features[b, parent[b]] followed by
+ * the 0/1 subset of the host's class id action[b] (clamped into range like hk_decode_host_class)           */
+int hk_search_expand_gather(const void* embeddings, const void* features, const int32_t* parent,
+                            const int32_t* action, void* obs_out, void* agent_feat_out, int batch,
+                            int num_nodes, int max_points, int dim, void* stream);
+/* axis_out[b] = argmax_k of logits[b, k] over the coordinates k of the subset of class id action[b]
+ * (jax/util.py:287-327: the agent's action mask + argmax; first maximum, NaN beats every number)       */
+int hk_search_masked_argmax(const void* logits, const int32_t* action, int32_t* axis_out, int batch, int dim,
+                            void* stream);
+/* embeddings[b, node[b]] = obs[b]; features[b, node[b]] = feat[b]   (obs, feat: [B, E] float32)          */
+int hk_search_expand_scatter(const void* obs, const void* feat, const int32_t* node, void* embeddings,
+                             void* features, int batch, int num_nodes, int max_points, int dim, void* stream);
+
 /* ---- fixed host policy as its own operator: class id per game -------------------------- */
 /* flags: HK_SEM_JAX (default; all ordered pairs, isclose-degenerate pairs skipped, degenerate
  * game -> class 0) or HK_SEM_LIST (host.py:70-95: pairs i<j of the available rows in row order,

@@ -27,7 +27,8 @@ def make_trainer(**over):
     host_net, host_params = standin_mlp(m * d, 2 ** d - d - 1, 3, width=64)
     agent_net, agent_params = standin_mlp(m * d + d, d, 4, width=64)
     return HipTrainer(42, cfg, host_net=host_net, agent_net=agent_net, host_params=host_params,
-                      agent_params=agent_params, use_graph=over.get("use_graph", False))
+                      agent_params=agent_params, use_graph=over.get("use_graph", False),
+                      fused_expand=over.get("fused_expand", True))
 
 
 def legal_successor(obs_t, obs_next, m, d):
@@ -114,3 +115,63 @@ def test_compute_rho_and_validate():
     assert len(det2) == 8 and sum(det2) <= 256
     rhos, dets = t.validate(batch_size=128, num_of_loops=1, max_length=8, key=1)
     assert len(rhos) == 7 and all(len(x) == 8 for x in dets)
+
+
+def test_expand_operators_against_numpy():
+    """hk_search_expand_gather / hk_search_masked_argmax / hk_search_expand_scatter against index arithmetic in numpy
+    (class ids out of range are clamped like hk_decode_host_class; NaN logits win the argmax, first maximum otherwise)"""
+    import ctypes as C
+
+    from hironaka_amd._lib import check, lib
+    from hironaka_amd.host_action_preprocess import decode_table
+    L = lib()
+    rng = np.random.default_rng(3)
+    for (b, n, m, d) in ((1, 2, 4, 3), (37, 5, 20, 3), (300, 9, 10, 4)):
+        e = m * d
+        emb = torch.tensor(rng.standard_normal((b, n, e)), dtype=torch.float32, device="cuda")
+        feat = torch.tensor(rng.standard_normal((b, n, e)), dtype=torch.float32, device="cuda")
+        parent = torch.tensor(rng.integers(0, n, b), dtype=torch.int32, device="cuda")
+        ncls = 2 ** d - d - 1
+        action = torch.tensor(rng.integers(-1, ncls + 1, b), dtype=torch.int32, device="cuda")
+        obs = torch.empty((b, e), dtype=torch.float32, device="cuda")
+        af = torch.empty((b, e + d), dtype=torch.float32, device="cuda")
+        check(L.hk_search_expand_gather(emb.data_ptr(), feat.data_ptr(), parent.data_ptr(), action.data_ptr(),
+                                        obs.data_ptr(), af.data_ptr(), b, n, m, d, None), "gather")
+        rows = np.arange(b)
+        table = decode_table(d).cpu().numpy().astype(np.float32)
+        masks = table[np.clip(action.cpu().numpy(), 0, ncls - 1)]
+        assert np.array_equal(obs.cpu().numpy(), emb.cpu().numpy()[rows, parent.cpu().numpy()])
+        assert np.array_equal(af.cpu().numpy(),
+                              np.concatenate([feat.cpu().numpy()[rows, parent.cpu().numpy()], masks], axis=1))
+        logits = rng.standard_normal((b, d)).astype(np.float32)
+        logits[rng.random((b, d)) < 0.1] = np.nan
+        logits[rng.random((b, d)) < 0.1] = 0.5  # ties
+        lg = torch.tensor(logits, device="cuda")
+        axis = torch.empty(b, dtype=torch.int32, device="cuda")
+        check(L.hk_search_masked_argmax(lg.data_ptr(), action.data_ptr(), axis.data_ptr(), b, d, None), "argmax")
+        ref = torch.argmax(torch.where(torch.tensor(masks > 0.5), torch.tensor(logits), torch.tensor(-np.inf)), dim=1)
+        assert np.array_equal(axis.cpu().numpy(), ref.numpy().astype(np.int32))
+        node = torch.tensor(rng.integers(0, n, b), dtype=torch.int32, device="cuda")
+        o2 = torch.tensor(rng.standard_normal((b, e)), dtype=torch.float32, device="cuda")
+        f2 = torch.tensor(rng.standard_normal((b, e)), dtype=torch.float32, device="cuda")
+        emb_ref, feat_ref = emb.cpu().numpy().copy(), feat.cpu().numpy().copy()
+        emb_ref[rows, node.cpu().numpy()] = o2.cpu().numpy()
+        feat_ref[rows, node.cpu().numpy()] = f2.cpu().numpy()
+        check(L.hk_search_expand_scatter(o2.data_ptr(), f2.data_ptr(), node.data_ptr(), emb.data_ptr(),
+                                         feat.data_ptr(), b, n, m, d, None), "scatter")
+        assert np.array_equal(emb.cpu().numpy(), emb_ref) and np.array_equal(feat.cpu().numpy(), feat_ref)
+    assert L.hk_search_expand_gather(None, None, None, None, None, None, 4, 2, 4, 3, None) == A.HK_ERR_NULL
+    assert L.hk_search_masked_argmax(None, None, None, 4, 1, None) == A.HK_ERR_SHAPE
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_fused_expansion_equals_generic_path(use_graph):
+    """host-role simulate(): the expansions through HostExpander (gather / masked argmax / step / features / scatter
+    operators) give the rollout of the generic recurrent_fn (tensor-library glue) bit for bit"""
+    a = make_trainer(eval_batch_size=256, num_evaluations=12, use_graph=use_graph, fused_expand=True)
+    b = make_trainer(eval_batch_size=256, num_evaluations=12, use_graph=use_graph, fused_expand=False)
+    assert a.fused_expand and not b.fused_expand
+    for key in (3, 4):
+        x, y = a.simulate(key, "host"), b.simulate(key, "host")
+        for u, v in zip(x, y):
+            assert torch.equal(torch.nan_to_num(u, neginf=-1e30), torch.nan_to_num(v, neginf=-1e30))
