@@ -155,6 +155,9 @@ PROTOTYPES = {
     "hk_search_expand_gather": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "hk_search_masked_argmax": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),
     "hk_search_expand_scatter": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "hk_search_expand_gather_agent": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "hk_search_expand_scatter_agent": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "hk_search_mask_logits": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),
 }
 
 STATUS_TEXT = {

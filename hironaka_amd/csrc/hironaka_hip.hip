@@ -519,6 +519,43 @@ int hk_search_expand_scatter(const void* obs, const void* feat, const int32_t* n
                                batch, num_nodes, max_points * dim, (hipStream_t)stream);
 }
 
+int hk_search_expand_gather_agent(const void* embeddings, const int32_t* parent, void* points_out, void* coords_out,
+                                  int batch, int num_nodes, int max_points, int dim, void* stream) {
+  const int st = expand_shape_ok(batch, num_nodes, max_points, dim);
+  if (st != HK_OK) return st;
+  if (batch == 0) return HK_OK;
+  if (!embeddings || !parent || !points_out || !coords_out) return HK_ERR_NULL;
+  if (!aligned(embeddings, 4) || !aligned(parent, 4) || !aligned(points_out, 4) || !aligned(coords_out, 4))
+    return HK_ERR_ALIGN;
+  return launch_expand_gather_agent((const float*)embeddings, parent, (float*)points_out, (float*)coords_out, batch,
+                                    num_nodes, max_points * dim, dim, (hipStream_t)stream);
+}
+
+int hk_search_expand_scatter_agent(const void* points, const void* feat, const void* host_logits,
+                                   const int32_t* node, void* embeddings, void* features, void* agent_feat_out,
+                                   int32_t* class_out, int batch, int num_nodes, int max_points, int dim,
+                                   int num_classes, void* stream) {
+  const int st = expand_shape_ok(batch, num_nodes, max_points, dim);
+  if (st != HK_OK) return st;
+  if (num_classes < 1 || (int64_t)num_classes > ((int64_t)1 << dim) - dim - 1) return HK_ERR_SHAPE;
+  if (batch == 0) return HK_OK;
+  if (!points || !feat || !host_logits || !node || !embeddings || !features || !agent_feat_out) return HK_ERR_NULL;
+  if (!aligned(points, 4) || !aligned(feat, 4) || !aligned(host_logits, 4) || !aligned(node, 4) ||
+      !aligned(embeddings, 4) || !aligned(features, 4) || !aligned(agent_feat_out, 4) || !aligned(class_out, 4))
+    return HK_ERR_ALIGN;
+  return launch_expand_scatter_agent((const float*)points, (const float*)feat, (const float*)host_logits, node,
+                                     (float*)embeddings, (float*)features, (float*)agent_feat_out, class_out, batch,
+                                     num_nodes, max_points * dim, dim, num_classes, (hipStream_t)stream);
+}
+
+int hk_search_mask_logits(const void* logits, const int32_t* class_id, void* out, int batch, int dim, void* stream) {
+  if (batch < 0 || dim < 2 || dim > kMaxDim) return HK_ERR_SHAPE;
+  if (batch == 0) return HK_OK;
+  if (!logits || !class_id || !out) return HK_ERR_NULL;
+  if (!aligned(logits, 4) || !aligned(class_id, 4) || !aligned(out, 4)) return HK_ERR_ALIGN;
+  return launch_mask_logits((const float*)logits, class_id, (float*)out, batch, dim, (hipStream_t)stream);
+}
+
 int hk_zeillinger(const void* points, int64_t stride, int32_t* class_out, int batch,
                   int max_points, int dim, int dtype, uint32_t flags, void* stream) {
   int st = check_spec(batch, max_points, dim, dtype);

@@ -368,6 +368,103 @@ __global__ void expand_scatter_kernel(const float* obs, const float* feat_in, co
   else feat[row + (e - E)] = feat_in[(int64_t)g * E + (e - E)];
 }
 
+// ---- the same for an AGENT-role tree (recurrent_fn.py:105-121): a node's embedding is the agent observation, points
+// followed by the host's 0/1 subset ([B, N, E + d]); the features table holds the features of the points ([B, N, E]).
+// points_out [B, E], coords_out [B, d] = the two parts of embeddings[b, parent[b]] (what the step consumes)
+__global__ void expand_gather_agent_kernel(const float* emb, const int32_t* parent, float* points_out,
+                                           float* coords_out, int batch, int nodes, int E, int d) {
+  const int per = E + d;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)batch * per) return;
+  const int g = (int)(idx / per), e = (int)(idx % per);
+  int p = parent[g];
+  p = p < 0 ? 0 : (p >= nodes ? nodes - 1 : p);
+  const float v = emb[((int64_t)g * nodes + p) * per + e];
+  if (e < E) points_out[(int64_t)g * E + e] = v;
+  else coords_out[(int64_t)g * d + (e - E)] = v;
+}
+
+// the host's answer on the new points and the new node: class = argmax of host_logits [B, C] (first maximum, NaN
+// beats every number), mask = its subset;  embeddings[b, node[b]] = points ++ mask;  features[b, node[b]] = feat;
+// agent_feat_out [B, E + d] = feat ++ mask (the agent network's input);  class_out [B] = the class
+__global__ void expand_scatter_agent_kernel(const float* points, const float* feat_in, const float* host_logits,
+                                            const int32_t* node, float* emb, float* feat, float* agent_feat_out,
+                                            int32_t* class_out, int batch, int nodes, int E, int d, int C) {
+  const int per = 2 * E + d;  // E points, E features, d mask entries
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)batch * per) return;
+  const int g = (int)(idx / per), e = (int)(idx % per);
+  const int n = node[g];
+  const bool inside = n >= 0 && n < nodes;
+  const int64_t erow = ((int64_t)g * nodes + (inside ? n : 0)) * (E + d);
+  const int64_t frow = ((int64_t)g * nodes + (inside ? n : 0)) * E;
+  if (e < E) {
+    if (inside) emb[erow + e] = points[(int64_t)g * E + e];
+  } else if (e < 2 * E) {
+    const float v = feat_in[(int64_t)g * E + (e - E)];
+    if (inside) feat[frow + (e - E)] = v;
+    agent_feat_out[(int64_t)g * (E + d) + (e - E)] = v;
+  } else {
+    const int k = e - 2 * E;
+    int best = 0;
+    float bv = host_logits[(int64_t)g * C];
+    for (int c = 1; c < C; ++c) {
+      const float v = host_logits[(int64_t)g * C + c];
+      if ((v > bv) || (v != v && bv == bv)) {
+        best = c;
+        bv = v;
+      }
+    }
+    const int ncls = (int)((1ll << d) - d - 1);
+    const int cc = best >= ncls ? ncls - 1 : best;
+    const float bit = (float)((decode_class(cc, d) >> k) & 1u);
+    if (inside) emb[erow + E + k] = bit;
+    agent_feat_out[(int64_t)g * (E + d) + E + k] = bit;
+    if (k == 0 && class_out) class_out[g] = cc;
+  }
+}
+
+// the agent's action mask on its logits (jax/util.py:287-305, NaN-free form): out[b, k] = logits[b, k] if coordinate k
+// is in the subset of class_id[b], else -inf
+__global__ void mask_logits_kernel(const float* logits, const int32_t* class_id, float* out, int batch, int d) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)batch * d) return;
+  const int g = (int)(idx / d), k = (int)(idx % d);
+  const int ncls = (int)((1ll << d) - d - 1);
+  int c = class_id[g];
+  c = c < 0 ? 0 : (c >= ncls ? ncls - 1 : c);
+  out[idx] = ((decode_class(c, d) >> k) & 1u) ? logits[idx] : -INFINITY;
+}
+
+inline int launch_expand_gather_agent(const float* emb, const int32_t* parent, float* points_out, float* coords_out,
+                                      int batch, int nodes, int E, int d, hipStream_t stream) {
+  launch_prepare();
+  const int64_t total = (int64_t)batch * (E + d);
+  hipLaunchKernelGGL(expand_gather_agent_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, emb,
+                     parent, points_out, coords_out, batch, nodes, E, d);
+  return launch_status();
+}
+
+inline int launch_expand_scatter_agent(const float* points, const float* feat_in, const float* host_logits,
+                                       const int32_t* node, float* emb, float* feat, float* agent_feat_out,
+                                       int32_t* class_out, int batch, int nodes, int E, int d, int C,
+                                       hipStream_t stream) {
+  launch_prepare();
+  const int64_t total = (int64_t)batch * (2 * E + d);
+  hipLaunchKernelGGL(expand_scatter_agent_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, points,
+                     feat_in, host_logits, node, emb, feat, agent_feat_out, class_out, batch, nodes, E, d, C);
+  return launch_status();
+}
+
+inline int launch_mask_logits(const float* logits, const int32_t* class_id, float* out, int batch, int d,
+                              hipStream_t stream) {
+  launch_prepare();
+  const int64_t total = (int64_t)batch * d;
+  hipLaunchKernelGGL(mask_logits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, logits, class_id,
+                     out, batch, d);
+  return launch_status();
+}
+
 inline int launch_expand_gather(const float* emb, const float* feat, const int32_t* parent, const int32_t* action,
                                 float* obs_out, float* agent_feat_out, int batch, int nodes, int E, int d,
                                 hipStream_t stream) {

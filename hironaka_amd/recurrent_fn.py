@@ -97,10 +97,81 @@ class HostExpander:
                                  value=value.reshape(b))
 
 
+class AgentExpander:
+    """The same for an AGENT-role tree (recurrent_fn.py:105-121): embeddings are agent observations (points ++ the
+    host's subset); the agent's axis finishes the move, the host network answers on the new points, the agent
+    network (behind its action mask) evaluates the new observation:
+
+        hk_search_expand_gather_agent -> hk_step (float mask, int32 axis) -> hk_get_features -> host network
+        -> hk_search_expand_scatter_agent (host argmax, subset, new node, agent input) -> agent network
+        -> hk_search_mask_logits"""
+
+    def __init__(self, host_model: Callable, agent_model: Callable, spec: Tuple[int, int], discount: float,
+                 scale_observation: bool, reposition: bool, rescale_points: bool = False, reward_sign: float = -1.0):
+        from . import ops
+        self.host_model, self.agent_model = host_model, agent_model
+        self.m, self.d = spec
+        self.discount = discount
+        self.scale_observation = scale_observation
+        self.reward_sign = reward_sign
+        self.stages = ops.make_stages(shift=True, reposition=reposition, newton=True, rescale=rescale_points)
+
+    def accepts(self, root_embedding: torch.Tensor) -> bool:
+        return (root_embedding.is_cuda and root_embedding.dtype == torch.float32 and root_embedding.dim() == 2
+                and root_embedding.shape[1] == (self.m + 1) * self.d)
+
+    def begin(self, tree, root_embedding: torch.Tensor):
+        from . import ops
+        b, n, width = tree.embeddings.shape
+        e, d = self.m * self.d, self.d
+        dev = tree.embeddings.device
+        features = torch.zeros((b, n, e), dtype=torch.float32, device=dev)
+        features[:, 0] = ops.get_features(root_embedding.contiguous(), self.scale_observation, spec=(self.m, self.d))
+        return {"features": features,
+                "points": torch.empty((b, e), dtype=torch.float32, device=dev),
+                "coords": torch.empty((b, d), dtype=torch.float32, device=dev),
+                "agent_feat": torch.empty((b, e + d), dtype=torch.float32, device=dev),
+                "cls": torch.empty(b, dtype=torch.int32, device=dev),
+                "discount": torch.full((b,), self.discount, dtype=torch.float32, device=dev)}
+
+    def expand(self, params, key, tree, state, parent: torch.Tensor, action: torch.Tensor, node: torch.Tensor):
+        import ctypes as C
+
+        from . import ops
+        from ._lib import check, lib
+        (agent_params, *_), (host_params, *_) = params
+        b, n, _ = tree.embeddings.shape
+        m, d = self.m, self.d
+        e = m * d
+        L = lib()
+        stream = C.c_void_p(torch.cuda.current_stream(tree.embeddings.device).cuda_stream)
+        points, coords, agent_feat, cls = state["points"], state["coords"], state["agent_feat"], state["cls"]
+        features = state["features"]
+        check(L.hk_search_expand_gather_agent(tree.embeddings.data_ptr(), parent.data_ptr(), points.data_ptr(),
+                                              coords.data_ptr(), b, n, m, d, stream), "hk_search_expand_gather_agent")
+        res = ops.step(points, coords, action, stages=self.stages, spec=(m, d), want=("done", "prev_done", "reward"),
+                       reward_sign=self.reward_sign)
+        updated = res["points"].reshape(b, e)
+        feat = ops.get_features(updated, self.scale_observation, spec=(m, d))
+        host_logits, _ = self.host_model(feat, host_params)
+        host_logits = host_logits.to(torch.float32).contiguous()
+        check(L.hk_search_expand_scatter_agent(updated.data_ptr(), feat.data_ptr(), host_logits.data_ptr(),
+                                               node.data_ptr(), tree.embeddings.data_ptr(), features.data_ptr(),
+                                               agent_feat.data_ptr(), cls.data_ptr(), b, n, m, d,
+                                               host_logits.shape[1], stream), "hk_search_expand_scatter_agent")
+        logits, value = self.agent_model(agent_feat, agent_params)
+        logits = logits.to(torch.float32).contiguous()
+        prior = torch.empty_like(logits)
+        check(L.hk_search_mask_logits(logits.data_ptr(), cls.data_ptr(), prior.data_ptr(), b, d, stream),
+              "hk_search_mask_logits")
+        return RecurrentFnOutput(reward=res["reward"], discount=state["discount"], prior_logits=prior,
+                                 value=value.reshape(b))
+
+
 def get_recurrent_fn_for_role(role: str, role_fn: Callable, opponent_action_fn: Callable, reward_fn: Callable,
                               spec: Tuple[int, int], discount: float = 0.99, dtype=torch.float32,
                               rescale_points: bool = False, reposition: bool = False,
-                              expander: "HostExpander | None" = None) -> Callable:
+                              expander: "HostExpander | AgentExpander | None" = None) -> Callable:
     """recurrent_fn.py:17-123.
     role_fn(observations, *args, key=...) -> (policy_prior, value_prior) of the player under evaluation;
     opponent_action_fn(observations, *args, key=...) -> one-hot actions of the fixed opponent;
@@ -159,7 +230,9 @@ def get_recurrent_fn_for_role(role: str, role_fn: Callable, opponent_action_fn: 
         return out, next_observations
 
     # (not in the reference) a search loop that knows about it runs the expansion through the fused operators
-    recurrent_fn.expander = expander if role == "host" else None
+    if expander is not None and not isinstance(expander, HostExpander if role == "host" else AgentExpander):
+        raise TypeError(f"a {role}-role tree cannot expand through {type(expander).__name__}")
+    recurrent_fn.expander = expander
     return recurrent_fn
 
 

@@ -37,7 +37,7 @@ from .host_action_preprocess import get_batch_decode_from_one_hot
 from .players import (all_coord_host_fn, choose_first_agent_fn, choose_last_agent_fn, get_host_with_flattened_obs,
                       get_name, random_agent_fn, random_host_fn, zeillinger_fn)
 from .rollout import compute_rho as _compute_rho
-from .recurrent_fn import HostExpander
+from .recurrent_fn import AgentExpander, HostExpander
 from .rollout import rollout_postprocess as _rollout_postprocess
 from .simulation_fn import get_evaluation_loop, get_simulation
 
@@ -203,11 +203,11 @@ class HipTrainer:
             # one hipGraph per search: only where nothing inside synchronises with the host (an opponent that is
             # itself a search does)
             "use_graph": self.use_graph and not mcts_opponent,
-            "expander": (HostExpander(self.host_model, self.agent_model, spec, self.discount, self.scale_observation,
-                                      self.reposition, rescale_points=False,
-                                      reward_sign=getattr(self.host_reward_fn, "hk_reward_sign", 1.0))
-                         if role == "host" and own_policies and self.fused_expand and self.dtype == torch.float32
-                         else None),
+            "expander": ((HostExpander if role == "host" else AgentExpander)(
+                             self.host_model, self.agent_model, spec, self.discount, self.scale_observation,
+                             self.reposition, rescale_points=False,
+                             reward_sign=getattr(getattr(self, f"{role}_reward_fn"), "hk_reward_sign"))
+                         if own_policies and self.fused_expand and self.dtype == torch.float32 else None),
         }
         eval_loop_with_gumbel = get_evaluation_loop(gumbel_scale=self.gumbel_scale, **eval_loop_config)
         eval_loop = get_evaluation_loop(gumbel_scale=0.0, **eval_loop_config)

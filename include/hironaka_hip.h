@@ -288,6 +288,24 @@ int hk_search_masked_argmax(const void* logits, const int32_t* action, int32_t* 
 int hk_search_expand_scatter(const void* obs, const void* feat, const int32_t* node, void* embeddings,
                              void* features, int batch, int num_nodes, int max_points, int dim, void* stream);
 
+/* The same for an AGENT-role tree (recurrent_fn.py:105-121): embeddings [B, N, E + dim] hold the agent observation
+ * (points followed by the host's 0/1 subset), features [B, N, E] the features of the points.  One expansion =
+ * hk_search_expand_gather_agent -> hk_step (float mask, the agent's axis) -> hk_get_features -> host network ->
+ * hk_search_expand_scatter_agent -> agent network -> hk_search_mask_logits.                                   */
+/* points_out [B, E], coords_out [B, dim] = the two parts of embeddings[b, parent[b]]                          */
+int hk_search_expand_gather_agent(const void* embeddings, const int32_t* parent, void* points_out, void* coords_out,
+                                  int batch, int num_nodes, int max_points, int dim, void* stream);
+/* class = argmax_c host_logits[b, c] (first maximum, NaN beats every number; num_classes <= 2^dim - dim - 1),
+ * mask = its subset; embeddings[b, node[b]] = points[b] ++ mask; features[b, node[b]] = feat[b];
+ * agent_feat_out [B, E + dim] = feat[b] ++ mask; class_out [B] (or NULL) = class                              */
+int hk_search_expand_scatter_agent(const void* points, const void* feat, const void* host_logits,
+                                   const int32_t* node, void* embeddings, void* features, void* agent_feat_out,
+                                   int32_t* class_out, int batch, int num_nodes, int max_points, int dim,
+                                   int num_classes, void* stream);
+/* out[b, k] = logits[b, k] if coordinate k belongs to the subset of class_id[b], else -inf (the agent's action
+ * mask, jax/util.py:287-305 in its NaN-free form); out may equal logits                                       */
+int hk_search_mask_logits(const void* logits, const int32_t* class_id, void* out, int batch, int dim, void* stream);
+
 /* ---- fixed host policy as its own operator: class id per game -------------------------- */
 /* flags: HK_SEM_JAX (default; all ordered pairs, isclose-degenerate pairs skipped, degenerate
  * game -> class 0) or HK_SEM_LIST (host.py:70-95: pairs i<j of the available rows in row order,

@@ -14,14 +14,15 @@ for fused in (True, False):
     agent_net, agent_params = standin_mlp(m * d + d, d, 4)
     t = HipTrainer(1, cfg, host_net=host_net, agent_net=agent_net, host_params=host_params, agent_params=agent_params,
                    use_graph=True, fused_expand=fused)
-    t.simulate(0, "host")
-    torch.cuda.synchronize()
-    ts = []
-    for r in range(5):
-        t0 = time.perf_counter()
-        t.simulate(r + 1, "host")
+    for role in ("host", "agent"):
+        t.simulate(0, role)
         torch.cuda.synchronize()
-        ts.append(time.perf_counter() - t0)
-    ts.sort()
-    print(f"fused_expand={fused}: simulate() median {ts[2]*1e3:.1f} ms  min {ts[0]*1e3:.1f} ms "
-          f"({8192*20*32/ts[2]/1e6:.1f} M search env-steps/s)", flush=True)
+        ts = []
+        for r in range(5):
+            t0 = time.perf_counter()
+            t.simulate(r + 1, role)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        print(f"fused_expand={fused} role={role}: simulate() median {ts[2]*1e3:.1f} ms  min {ts[0]*1e3:.1f} ms "
+              f"({8192*20*32/ts[2]/1e6:.1f} M search env-steps/s)", flush=True)

@@ -160,18 +160,52 @@ def test_expand_operators_against_numpy():
         check(L.hk_search_expand_scatter(o2.data_ptr(), f2.data_ptr(), node.data_ptr(), emb.data_ptr(),
                                          feat.data_ptr(), b, n, m, d, None), "scatter")
         assert np.array_equal(emb.cpu().numpy(), emb_ref) and np.array_equal(feat.cpu().numpy(), feat_ref)
+        # the agent-role tree's operators
+        ncl = 2 ** d - d - 1
+        embA = torch.tensor(rng.standard_normal((b, n, e + d)), dtype=torch.float32, device="cuda")
+        pts = torch.empty((b, e), dtype=torch.float32, device="cuda")
+        crd = torch.empty((b, d), dtype=torch.float32, device="cuda")
+        check(L.hk_search_expand_gather_agent(embA.data_ptr(), parent.data_ptr(), pts.data_ptr(), crd.data_ptr(),
+                                              b, n, m, d, None), "gather_agent")
+        rec = embA.cpu().numpy()[rows, parent.cpu().numpy()]
+        assert np.array_equal(pts.cpu().numpy(), rec[:, :e]) and np.array_equal(crd.cpu().numpy(), rec[:, e:])
+        hl = rng.standard_normal((b, ncl)).astype(np.float32)
+        hl[rng.random((b, ncl)) < 0.1] = np.nan
+        hl[rng.random((b, ncl)) < 0.1] = 0.25
+        hlg = torch.tensor(hl, device="cuda")
+        afeat = torch.empty((b, e + d), dtype=torch.float32, device="cuda")
+        cls = torch.empty(b, dtype=torch.int32, device="cuda")
+        featA = torch.tensor(rng.standard_normal((b, n, e)), dtype=torch.float32, device="cuda")
+        embA_ref, featA_ref = embA.cpu().numpy().copy(), featA.cpu().numpy().copy()
+        check(L.hk_search_expand_scatter_agent(o2.data_ptr(), f2.data_ptr(), hlg.data_ptr(), node.data_ptr(),
+                                               embA.data_ptr(), featA.data_ptr(), afeat.data_ptr(), cls.data_ptr(),
+                                               b, n, m, d, ncl, None), "scatter_agent")
+        cref = torch.argmax(torch.tensor(hl), dim=1).numpy()
+        mref = table[cref]
+        embA_ref[rows, node.cpu().numpy()] = np.concatenate([o2.cpu().numpy(), mref], axis=1)
+        featA_ref[rows, node.cpu().numpy()] = f2.cpu().numpy()
+        assert np.array_equal(cls.cpu().numpy(), cref.astype(np.int32))
+        assert np.array_equal(embA.cpu().numpy(), embA_ref) and np.array_equal(featA.cpu().numpy(), featA_ref)
+        assert np.array_equal(afeat.cpu().numpy(), np.concatenate([f2.cpu().numpy(), mref], axis=1))
+        out = torch.empty_like(lg)
+        check(L.hk_search_mask_logits(lg.data_ptr(), cls.data_ptr(), out.data_ptr(), b, d, None), "mask_logits")
+        want = np.where(mref > 0.5, logits, -np.inf).astype(np.float32)
+        assert np.array_equal(out.cpu().numpy(), want, equal_nan=True)
     assert L.hk_search_expand_gather(None, None, None, None, None, None, 4, 2, 4, 3, None) == A.HK_ERR_NULL
+    assert L.hk_search_expand_scatter_agent(None, None, None, None, None, None, None, None, 4, 2, 4, 3, 9, None) \
+        == A.HK_ERR_SHAPE
     assert L.hk_search_masked_argmax(None, None, None, 4, 1, None) == A.HK_ERR_SHAPE
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_fused_expansion_equals_generic_path(use_graph):
-    """host-role simulate(): the expansions through HostExpander (gather / masked argmax / step / features / scatter
-    operators) give the rollout of the generic recurrent_fn (tensor-library glue) bit for bit"""
+@pytest.mark.parametrize("role", ["host", "agent"])
+def test_fused_expansion_equals_generic_path(role, use_graph):
+    """simulate(): the expansions through HostExpander / AgentExpander (gather / argmax / step / features / scatter /
+    mask operators) give the rollout of the generic recurrent_fn (tensor-library glue) bit for bit"""
     a = make_trainer(eval_batch_size=256, num_evaluations=12, use_graph=use_graph, fused_expand=True)
     b = make_trainer(eval_batch_size=256, num_evaluations=12, use_graph=use_graph, fused_expand=False)
     assert a.fused_expand and not b.fused_expand
     for key in (3, 4):
-        x, y = a.simulate(key, "host"), b.simulate(key, "host")
+        x, y = a.simulate(key, role), b.simulate(key, role)
         for u, v in zip(x, y):
             assert torch.equal(torch.nan_to_num(u, neginf=-1e30), torch.nan_to_num(v, neginf=-1e30))
