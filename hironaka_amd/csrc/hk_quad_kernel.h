@@ -71,6 +71,10 @@ struct QuadGeom {
   static constexpr int kRegion = kBig ? kQuadGames * (N > M * CW ? N : M * CW) : kImage + kCompact;
   static constexpr int kGameStride = kBig ? (N > M * CW ? N : M * CW) : N;  // floats between two games' images
   static constexpr int kStoreBatch = QL < 12 ? QL : 10;                // slab chunks per store round
+  // waves per SIMD the register budget is set for: what the LDS footprint lets a CU hold (160 KB; four waves per
+  // workgroup, one per SIMD), at most four; two for the large games
+  static constexpr int kLdsPerGroup = 4 * (kRegion * 4 + kQuadGames * D * 4);
+  static constexpr int kWavesPerSimd = kBig ? 2 : ((160 * 1024 / kLdsPerGroup) < 4 ? (160 * 1024 / kLdsPerGroup) : 4);
   // buckets of straight-line bodies (slots per lane)
   static constexpr int next_bucket(int nb) { return nb < 6 ? nb + 1 : (nb < 10 ? nb + 2 : nb + 3); }
   static_assert(!kBig || kGameStride == N, "the aliased layout assumes the compact rows fit the image");
@@ -625,7 +629,7 @@ __device__ __forceinline__ void quad_actions_decode(const QuadActions<D, ACT>& a
 // HOT: kHotJax = the JAX trainer's take_actions (shift + reposition + Newton polytope, JAX semantics) compiled in.
 // register budget: four waves per SIMD (<= 128 VGPRs), three for the large games (<= 168; their LDS allows no more)
 template <int M, int D, int HOT, int WPB, int ACT>
-__global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kBig ? 2 : 4)) void quad_kernel(const float* in0, int64_t in_stride0, int batch0,
+__global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void quad_kernel(const float* in0, int64_t in_stride0, int batch0,
                                                            const Params prm) {
   using G = QuadGeom<M, D>;
   constexpr int R = G::R;

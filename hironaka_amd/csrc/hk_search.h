@@ -119,78 +119,158 @@ __device__ inline int search_root_argmax(const SearchTree& t, int64_t b, const d
   return best;
 }
 
+// ---- the descent with ONE LANE PER ACTION (AMAX lanes per game).  With one lane per game every level of the walk
+// was 2 A double-precision exp() calls one after the other behind a dependent load -- 16 us per simulation for 8192
+// games, the largest HIP kernel of a search; here the A exponentials of a level run side by side and a level's loads
+// are one coalesced request per array.  Sums over the actions keep the sequential order of the one-lane code (every
+// lane adds the group's values in order 0 .. A-1: bit-identical results); maxima are order-free.
+template <int AMAX>
+__device__ inline double grp_get(double v, int src) { return __shfl(v, src, AMAX); }
+template <int AMAX>
+__device__ inline double grp_max(double v) {
+#pragma unroll
+  for (int off = AMAX / 2; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, AMAX));
+  return v;
+}
+template <int AMAX>
+__device__ inline double grp_min(double v) {
+#pragma unroll
+  for (int off = AMAX / 2; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, AMAX));
+  return v;
+}
+template <int AMAX>
+__device__ inline int grp_isum(int v) {
+#pragma unroll
+  for (int off = AMAX / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, AMAX);
+  return v;
+}
+template <int AMAX>
+__device__ inline int grp_imax(int v) {
+#pragma unroll
+  for (int off = AMAX / 2; off > 0; off >>= 1) {
+    const int o = __shfl_xor(v, off, AMAX);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+template <int AMAX>
+__device__ inline double grp_seq_sum(double v, int A) {  // v_0 + v_1 + ... in that order (lanes >= A hold 0)
+  double s = 0.0;
+  for (int k = 0; k < A; ++k) s += grp_get<AMAX>(v, k);
+  return s;
+}
+template <int AMAX>
+__device__ inline int grp_first_argmax(double v, int A) {  // the one-lane loop: `if (s > best_s)` over a = 0 .. A-1
+  int best = 0;
+  double best_s = -INFINITY;
+  for (int k = 0; k < A; ++k) {
+    const double sk = grp_get<AMAX>(v, k);
+    if (sk > best_s) {
+      best_s = sk;
+      best = k;
+    }
+  }
+  return best;
+}
+
+// completed Q-value of MY action at node n (search_completed_q, one lane per action); also returns the lane's prior
+// logit, its visit count, the group's maximum logit and total visit count
+template <int AMAX>
+__device__ inline double lane_completed_q(const SearchTree& t, int64_t b, int n, int a, double& logit_out,
+                                          int& visits_out, double& mx_out, double& sum_visits_out) {
+  const int A = t.num_actions;
+  const bool on = a < A;
+  const int64_t e = (b * t.num_nodes + n) * A + (on ? a : 0);
+  const double logit = on ? (double)t.children_prior_logits[e] : -INFINITY;
+  const int visits = on ? t.children_visits[e] : 0;
+  double cq = on ? (double)t.children_rewards[e] + (double)t.children_discounts[e] * (double)t.children_values[e] : 0.0;
+  const double raw = (double)t.raw_values[b * t.num_nodes + n];
+  const double mx = grp_max<AMAX>(logit);
+  double p = on ? exp(logit - mx) : 0.0;
+  const double den = grp_seq_sum<AMAX>(p, A);
+  p = on ? fmax(1.1754943508222875e-38, p / den) : 0.0;
+  const double sum_probs = grp_seq_sum<AMAX>(visits > 0 ? p : 0.0, A);
+  const double sum_visits = (double)grp_isum<AMAX>(visits);
+  const int maxvisit = grp_imax<AMAX>(visits);
+  const double weighted_q = grp_seq_sum<AMAX>(visits > 0 ? p * cq / sum_probs : 0.0, A);
+  const double value = (raw + sum_visits * weighted_q) / (sum_visits + 1.0);
+  if (!(visits > 0)) cq = value;
+  const double lo = grp_min<AMAX>(on ? cq : INFINITY), hi = grp_max<AMAX>(on ? cq : -INFINITY);
+  const double scale = (50.0 + (double)maxvisit) * 0.1;
+  const double span = fmax(hi - lo, 1e-8);
+  logit_out = logit;
+  visits_out = visits;
+  mx_out = mx;
+  sum_visits_out = sum_visits;
+  return scale * ((cq - lo) / span);
+}
+
 // one simulation's descent: the edge (parent, action) to expand and the node index the expansion writes
 // (the existing child at the depth limit, else `next_free`)
 template <int AMAX>
-__global__ __launch_bounds__(64) void search_select_kernel(SearchTree t, const float* gumbel, const uint8_t* invalid,
-                                                           const int32_t* table, int max_considered,
-                                                           int num_simulations, int max_depth, int next_free,
-                                                           int32_t* parent_out, int32_t* action_out,
-                                                           int32_t* node_out) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= t.batch) return;
+__device__ inline void search_descend(const SearchTree& t, int64_t b, int a, const float* gumbel,
+                                      const uint8_t* invalid, const int32_t* table, int max_considered,
+                                      int num_simulations, int max_depth, int next_free, int32_t* parent_out,
+                                      int32_t* action_out, int32_t* node_out) {
   const int A = t.num_actions;
-  double cq[AMAX];
+  const bool on = a < A;
   // root: sequential halving over the Gumbel-top-k actions
-  search_completed_q<AMAX>(t, b, 0, cq);
-  int num_valid = A, sim_index = 0;
-  for (int a = 0; a < A; ++a) {
-    if (invalid && invalid[b * A + a]) --num_valid;
-    sim_index += t.children_visits[b * t.num_nodes * A + a];
-  }
+  double logit, mx, sum_visits;
+  int visits;
+  double cq = lane_completed_q<AMAX>(t, b, 0, a, logit, visits, mx, sum_visits);
+  const bool bad = on && invalid && invalid[b * A + a];
+  const int num_valid = A - grp_isum<AMAX>(bad ? 1 : 0);
+  const int sim_index = grp_isum<AMAX>(visits);
   const int num_considered = max_considered < num_valid ? max_considered : num_valid;
   const int considered_visit = table[(int64_t)num_considered * num_simulations + sim_index];
+  double s = -INFINITY;
+  if (on) {
+    s = fmax(-1e9, (double)gumbel[b * A + a] + (logit - mx) + cq);
+    if (visits != considered_visit) s = -INFINITY;
+    if (bad) s = -INFINITY;
+  }
   int node = 0;
-  int action = search_root_argmax<AMAX>(t, b, cq, gumbel, invalid, considered_visit);
+  int action = grp_first_argmax<AMAX>(s, A);
   int next = t.children_index[(b * t.num_nodes + node) * A + action];
   int depth = 0;
-  while (next != -1 && depth + 1 < max_depth) {
+  while (next != -1 && depth + 1 < max_depth) {  // (uniform inside a game's group of lanes)
     node = next;
     ++depth;
     // interior: argmax(softmax(logits + completed Q) - N / (1 + sum N))
-    search_completed_q<AMAX>(t, b, node, cq);
-    const int64_t e0 = (b * t.num_nodes + node) * A;
-    double mx = -INFINITY, sum_visits = 0.0;
-    double vis[AMAX];
-#pragma unroll
-    for (int a = 0; a < AMAX; ++a)
-      if (a < A) {
-        cq[a] += (double)t.children_prior_logits[e0 + a];
-        vis[a] = (double)t.children_visits[e0 + a];
-        mx = fmax(mx, cq[a]);
-        sum_visits += vis[a];
-      }
-    double den = 0.0;
-#pragma unroll
-    for (int a = 0; a < AMAX; ++a)
-      if (a < A) {
-        cq[a] = exp(cq[a] - mx);
-        den += cq[a];
-      }
-    double best_s = -INFINITY;
-    action = 0;
-#pragma unroll
-    for (int a = 0; a < AMAX; ++a)
-      if (a < A) {
-        const double s = cq[a] / den - vis[a] / (1.0 + sum_visits);
-        if (s > best_s) {
-          best_s = s;
-          action = a;
-        }
-      }
-    next = t.children_index[e0 + action];
+    cq = lane_completed_q<AMAX>(t, b, node, a, logit, visits, mx, sum_visits);
+    const double z = on ? cq + logit : -INFINITY;
+    const double mz = grp_max<AMAX>(z);
+    const double ez = on ? exp(z - mz) : 0.0;
+    const double den = grp_seq_sum<AMAX>(ez, A);
+    s = on ? ez / den - (double)visits / (1.0 + sum_visits) : -INFINITY;
+    action = grp_first_argmax<AMAX>(s, A);
+    next = t.children_index[(b * t.num_nodes + node) * A + action];
   }
-  parent_out[b] = node;
-  action_out[b] = action;
-  node_out[b] = next == -1 ? next_free : next;
+  if (a == 0) {
+    parent_out[b] = node;
+    action_out[b] = action;
+    node_out[b] = next == -1 ? next_free : next;
+  }
+}
+
+template <int AMAX>
+__global__ __launch_bounds__(256) void search_select_kernel(SearchTree t, const float* gumbel, const uint8_t* invalid,
+                                                            const int32_t* table, int max_considered,
+                                                            int num_simulations, int max_depth, int next_free,
+                                                            int32_t* parent_out, int32_t* action_out,
+                                                            int32_t* node_out) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int a = (int)(tid % AMAX);
+  const int64_t game = tid / AMAX;
+  if (game >= t.batch) return;  // (whole groups: a game's lanes stay together)
+  search_descend<AMAX>(t, game, a, gumbel, invalid, table, max_considered, num_simulations, max_depth, next_free,
+                       parent_out, action_out, node_out);
 }
 
 // expansion (the new node's statistics and its edge) + the backward pass to the root
-__global__ void search_backup_kernel(SearchTree t, const int32_t* parent_in, const int32_t* action_in,
-                                     const int32_t* node_in, const float* prior_logits, const float* value,
-                                     const float* reward, const float* discount) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= t.batch) return;
+__device__ inline void search_backup_game(const SearchTree& t, int64_t b, const int32_t* parent_in,
+                                          const int32_t* action_in, const int32_t* node_in, const float* prior_logits,
+                                          const float* value, const float* reward, const float* discount) {
   const int A = t.num_actions, N = t.num_nodes;
   const int parent = parent_in[b], action = action_in[b], node = node_in[b];
   for (int a = 0; a < A; ++a) t.children_prior_logits[(b * N + node) * A + a] = prior_logits[b * A + a];
@@ -217,6 +297,14 @@ __global__ void search_backup_kernel(SearchTree t, const int32_t* parent_in, con
     t.node_visits[b * N + p] += 1;
     index = p;
   }
+}
+
+__global__ void search_backup_kernel(SearchTree t, const int32_t* parent_in, const int32_t* action_in,
+                                     const int32_t* node_in, const float* prior_logits, const float* value,
+                                     const float* reward, const float* discount) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= t.batch) return;
+  search_backup_game(t, b, parent_in, action_in, node_in, prior_logits, value, reward, discount);
 }
 
 // the improved policy at the root after the last simulation: action (Gumbel argmax among the most
@@ -276,8 +364,9 @@ inline int launch_search_select(const SearchTree& t, const float* gumbel, const 
                                 hipStream_t stream) {
   launch_prepare();
 #define HK_CALL(AM)                                                                                               \
-  hipLaunchKernelGGL(search_select_kernel<AM>, dim3((t.batch + 63) / 64), dim3(64), 0, stream, t, gumbel, invalid, \
-                     table, max_considered, num_simulations, max_depth, next_free, parent_out, action_out, node_out)
+  hipLaunchKernelGGL(search_select_kernel<AM>, dim3((unsigned)(((int64_t)t.batch * AM + 255) / 256)), dim3(256), 0,  \
+                     stream, t, gumbel, invalid, table, max_considered, num_simulations, max_depth, next_free,     \
+                     parent_out, action_out, node_out)
   HK_SEARCH_DISPATCH(t.num_actions, HK_CALL);
 #undef HK_CALL
   return launch_status();

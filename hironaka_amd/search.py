@@ -7,9 +7,10 @@ fields (batch-first), `RootFnOutput`, `PolicyOutput(action, action_weights, sear
 `gumbel_muzero_policy(params, rng_key, root, recurrent_fn, num_simulations, ...)`.  Parity against mctx
 itself is UNPINNED; the kernels are pinned to oracle/search_oracle.py (tests/test_gpu_search.py).
 
-Per simulation the device runs: hk_search_select (one lane per game walks its tree) -> gather of the
-parent embeddings -> `recurrent_fn` (opponent policy + HIP environment step + the player's network) ->
-scatter of the new embeddings -> hk_search_backup.  No host synchronisation anywhere in the loop.
+Per simulation the device runs: hk_search_select (one lane per ACTION walks the game's tree) -> gather of the parent embeddings -> `recurrent_fn` (opponent
+policy + HIP environment step + the player's network) -> scatter of the new embeddings -> hk_search_backup; a recurrent_fn with an
+`expander` (recurrent_fn.HostExpander / AgentExpander) runs gather / step / scatter as fused operators.  No host
+synchronisation anywhere in the loop.
 """
 from __future__ import annotations
 
