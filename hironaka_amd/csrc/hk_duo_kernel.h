@@ -165,9 +165,36 @@ __device__ __forceinline__ uint32_t duo_scatter(const float (&q)[CH * D], float*
 }
 
 // ---- the stages on NB slots per lane ----------------------------------------------------------------------
-template <int CH, int D, int NB>
+template <int CH, int D, int NB, bool BIN = false>
 __device__ __forceinline__ void d_reposition(float (&q)[CH * D], unsigned flags) {
   const bool jax_sem = (flags & HK_SEM_MASK) == HK_SEM_JAX;
+  if constexpr (BIN) {
+    // Rollouts with in-kernel 0/1 subsets: every coordinate is >= +0 or the +inf of a hole (guarded at entry; sums,
+    // differences against the column minimum and quotients keep it so, and x - x is +0), so the float order is the
+    // unsigned order of the bit patterns: v_min_u32 with the partner's value as a DPP operand -- the float minimum of
+    // values of unknown origin costs a canonicalising v_max x, x per operand (5 instructions per column at one slot
+    // per lane, now 1).  A column without live rows subtracts 0; a minimum of 0 subtracts itself (JAX and torch
+    // semantics agree there).
+    uint32_t mb[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) mb[k] = __float_as_uint(q[k]);
+#pragma unroll
+    for (int r = 1; r < NB; ++r)
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const uint32_t w = __float_as_uint(q[r * D + k]);
+        mb[k] = w < mb[k] ? w : mb[k];
+      }
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const uint32_t o = (uint32_t)duo_other_i((int)mb[k]);
+      mb[k] = o < mb[k] ? o : mb[k];
+      const float sub = (mb[k] == 0x7F800000u) ? 0.0f : __uint_as_float(mb[k]);
+#pragma unroll
+      for (int r = 0; r < NB; ++r) q[r * D + k] = q[r * D + k] - sub;
+    }
+    return;
+  }
   float mn[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) mn[k] = INFINITY;
@@ -216,17 +243,18 @@ __device__ __forceinline__ void d_rescale(float (&q)[CH * D], unsigned flags) {
 // acc[] <= 0 marks my row removed; oth[] <= 0 marks the partner's slot removed (sent back at the end).
 template <int CH, int D, int NB>
 __device__ __forceinline__ void d_newton(float (&q)[CH * D], int h) {
+  // (the accumulators take their FIRST contribution by assignment -- which one that is, is known at compile time --
+  // instead of starting at +inf: min(+inf, x) was an instruction per slot, two with the canonicalising v_max)
   float acc[NB], oth[NB];
-#pragma unroll
-  for (int r = 0; r < NB; ++r) acc[r] = oth[r] = INFINITY;
 #pragma unroll
   for (int i = 0; i + 1 < NB; ++i) {
 #pragma unroll
     for (int j = i + 1; j < NB; ++j) {
       float t, u;
       diff_extrema<D>(&q[i * D], &q[j * D], t, u);
-      acc[j] = hk_fmin(acc[j], t);
-      acc[i] = hk_fmin(acc[i], (t > 0.0f) ? -u : 1.0f);
+      const float vi = (t > 0.0f) ? -u : 1.0f;
+      acc[j] = (i == 0) ? t : hk_fmin(acc[j], t);
+      acc[i] = (i == 0 && j == 1) ? vi : hk_fmin(acc[i], vi);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -239,8 +267,9 @@ __device__ __forceinline__ void d_newton(float (&q)[CH * D], int h) {
     {  // diagonal
       float t, u;
       diff_extrema<D>(&q[b * D], o, t, u);
-      acc[b] = hk_fmin(acc[b], (t > 0.0f || late) ? -u : 1.0f);
-      oth[b] = hk_fmin(oth[b], (u < 0.0f || !late) ? t : 1.0f);
+      const float va = (t > 0.0f || late) ? -u : 1.0f;
+      acc[b] = (NB == 1) ? va : hk_fmin(acc[b], va);
+      oth[b] = (u < 0.0f || !late) ? t : 1.0f;
     }
 #pragma unroll
     for (int a = 0; a < b; ++a) {
@@ -253,7 +282,9 @@ __device__ __forceinline__ void d_newton(float (&q)[CH * D], int h) {
   }
 #pragma unroll
   for (int r = 0; r < NB; ++r) {
-    const bool removed = hk_fmin(acc[r], duo_other(oth[r])) <= 0.0f;
+    // (two compares, not a float minimum of a value that came through DPP: that one is canonicalised first)
+    const bool r0 = acc[r] <= 0.0f, r1 = duo_other(oth[r]) <= 0.0f;
+    const bool removed = r0 || r1;
 #pragma unroll
     for (int k = 0; k < D; ++k) q[r * D + k] = removed ? INFINITY : q[r * D + k];
   }
@@ -267,7 +298,7 @@ __device__ __forceinline__ int d_stages(float (&q)[CH * D], const float (&c)[D],
     if constexpr (BIN) b_shift_mask<CH, D, NB>(q, cmask, axis, np, flags);
     else b_shift<CH, D, NB>(q, c, axis, np, flags);
   }
-  if (stages & HK_STAGE_REPOSITION) d_reposition<CH, D, NB>(q, flags);
+  if (stages & HK_STAGE_REPOSITION) d_reposition<CH, D, NB, BIN>(q, flags);
   if (stages & HK_STAGE_NEWTON) d_newton<CH, D, NB>(q, h);
   if (stages & HK_STAGE_RESCALE) d_rescale<CH, D, NB>(q, flags);
   int n = 0;

@@ -278,9 +278,30 @@ __device__ __forceinline__ void b_shift_mask(float (&q)[C * D], uint32_t cmask, 
   }
 }
 
-template <int C, int D, int NB>
+template <int C, int D, int NB, bool BIN = false>
 __device__ __forceinline__ void b_reposition(float (&q)[C * D], unsigned flags) {
   const bool jax_sem = (flags & HK_SEM_MASK) == HK_SEM_JAX;
+  if constexpr (BIN) {
+    // rollouts with in-kernel 0/1 subsets: coordinates are >= +0 or the +inf of a hole, so the float order is the
+    // unsigned order of the bit patterns (v_min_u32 / v_min3_u32, no canonicalising v_max x, x; see d_reposition)
+    uint32_t mb[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) mb[k] = __float_as_uint(q[k]);
+#pragma unroll
+    for (int r = 1; r < NB; ++r)
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const uint32_t w = __float_as_uint(q[r * D + k]);
+        mb[k] = w < mb[k] ? w : mb[k];
+      }
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const float sub = (mb[k] == 0x7F800000u) ? 0.0f : __uint_as_float(mb[k]);
+#pragma unroll
+      for (int r = 0; r < NB; ++r) q[r * D + k] = q[r * D + k] - sub;
+    }
+    return;
+  }
   float mn[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) mn[k] = INFINITY;
@@ -300,17 +321,19 @@ __device__ __forceinline__ void b_reposition(float (&q)[C * D], unsigned flags) 
 
 template <int C, int D, int NB>
 __device__ __forceinline__ void b_newton(float (&q)[C * D]) {
+  if constexpr (NB < 2) return;  // (one row: nothing to compare)
+  // (every accumulator takes its first contribution by assignment -- known at compile time -- instead of starting at
+  // +inf: no min(+inf, x))
   float acc[NB];
-#pragma unroll
-  for (int r = 0; r < NB; ++r) acc[r] = INFINITY;
 #pragma unroll
   for (int i = 0; i + 1 < NB; ++i) {
 #pragma unroll
     for (int j = i + 1; j < NB; ++j) {
       float t, u;
       diff_extrema<D>(&q[i * D], &q[j * D], t, u);
-      acc[j] = hk_fmin(acc[j], t);
-      acc[i] = hk_fmin(acc[i], (t > 0.0f) ? -u : 1.0f);
+      const float vi = (t > 0.0f) ? -u : 1.0f;
+      acc[j] = (i == 0) ? t : hk_fmin(acc[j], t);
+      acc[i] = (i == 0 && j == 1) ? vi : hk_fmin(acc[i], vi);
     }
     // the pairs are all independent; left alone the scheduler interleaves hundreds of them and the
     // differences in flight overflow the register file.  One row of pairs at a time is plenty of ILP.
@@ -352,7 +375,7 @@ __device__ __forceinline__ int b_stages(float (&q)[C * D], const float (&c)[D], 
     if constexpr (BIN) b_shift_mask<C, D, NB>(q, cmask, axis, np, flags);
     else b_shift<C, D, NB>(q, c, axis, np, flags);
   }
-  if (stages & HK_STAGE_REPOSITION) b_reposition<C, D, NB>(q, flags);
+  if (stages & HK_STAGE_REPOSITION) b_reposition<C, D, NB, BIN>(q, flags);
   if (stages & HK_STAGE_NEWTON) b_newton<C, D, NB>(q);
   if (stages & HK_STAGE_RESCALE) b_rescale<C, D, NB>(q, flags);
   int n = 0;

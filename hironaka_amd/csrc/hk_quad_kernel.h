@@ -243,20 +243,24 @@ __device__ __forceinline__ void qd_extrema(const float* a, const float* b, float
 //   other earlier: other removed iff t <= 0 and u < 0;  mine removed iff u >= 0
 // `acc` / `oth` are running minima; <= 0 means removed.  ORDER: +1 mine earlier, -1 other earlier, 0: `late` decides
 // at run time (true: the other row is the earlier one).
-template <int D, int ORDER>
+template <int D, int ORDER, bool ACC_FIRST = false, bool OTH_FIRST = false>
 __device__ __forceinline__ void qd_pair(const float* mine, const float* other, float& acc, float& oth, bool late) {
   float t, u;
   qd_extrema<D>(mine, other, t, u);
+  float vo, va;
   if (ORDER > 0) {
-    oth = hk_fmin(oth, t);
-    acc = hk_fmin(acc, (t > 0.0f) ? -u : 1.0f);
+    vo = t;
+    va = (t > 0.0f) ? -u : 1.0f;
   } else if (ORDER < 0) {
-    oth = hk_fmin(oth, (u < 0.0f) ? t : 1.0f);
-    acc = hk_fmin(acc, -u);
+    vo = (u < 0.0f) ? t : 1.0f;
+    va = -u;
   } else {
-    oth = hk_fmin(oth, (u < 0.0f || !late) ? t : 1.0f);
-    acc = hk_fmin(acc, (t > 0.0f || late) ? -u : 1.0f);
+    vo = (u < 0.0f || !late) ? t : 1.0f;
+    va = (t > 0.0f || late) ? -u : 1.0f;
   }
+  // (*_FIRST: the accumulator's first contribution is an assignment -- no +inf start, no min(+inf, x))
+  oth = OTH_FIRST ? vo : hk_fmin(oth, vo);
+  acc = ACC_FIRST ? va : hk_fmin(acc, va);
 }
 
 // _jax_ops.py:15-73 across the quad.  Rank of (slot s, lane j) = 4 s + j.
@@ -265,17 +269,17 @@ __device__ __forceinline__ void qd_pair(const float* mine, const float* other, f
 //   lane two up, a <= b:             mine earlier iff a < b, or a == b and j < 2
 template <int R, int D, int NB>
 __device__ __forceinline__ void qd_newton(float (&q)[R * D], int j) {
+  // (accumulators: first contribution by assignment, known at compile time; see d_newton)
   float acc[NB], o1[NB], o2[NB];
-#pragma unroll
-  for (int r = 0; r < NB; ++r) acc[r] = o1[r] = o2[r] = INFINITY;
 #pragma unroll
   for (int a = 0; a + 1 < NB; ++a) {
 #pragma unroll
     for (int b = a + 1; b < NB; ++b) {
       float t, u;
       qd_extrema<D>(&q[a * D], &q[b * D], t, u);
-      acc[b] = hk_fmin(acc[b], t);
-      acc[a] = hk_fmin(acc[a], (t > 0.0f) ? -u : 1.0f);
+      const float va = (t > 0.0f) ? -u : 1.0f;
+      acc[b] = (a == 0) ? t : hk_fmin(acc[b], t);
+      acc[a] = (a == 0 && b == 1) ? va : hk_fmin(acc[a], va);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -288,27 +292,32 @@ __device__ __forceinline__ void qd_newton(float (&q)[R * D], int j) {
       p1[k] = qperm<kQuadUp1>(q[b * D + k]);
       p2[k] = qperm<kQuadUp2>(q[b * D + k]);
     }
-#pragma unroll
-    for (int a = 0; a < NB; ++a) {
+    unrolled_while<0, NB>([&](auto ac) {  // (compile-time a: which contribution is an accumulator's first)
+      constexpr int a = decltype(ac)::value;
+      constexpr bool of = a == 0;        // o1[b], o2[b]: slot a = 0 comes first (0 <= b)
+      constexpr bool af = NB == 1;       // acc[a]: the own-slot triangle came first, unless there is none
+      // (b is a run-time loop index of an unrolled loop; the three cases are resolved when it is unrolled)
       if (a < b) {
-        qd_pair<D, +1>(&q[a * D], p1, acc[a], o1[b], false);
-        qd_pair<D, +1>(&q[a * D], p2, acc[a], o2[b], false);
+        qd_pair<D, +1, false, of>(&q[a * D], p1, acc[a], o1[b], false);
+        qd_pair<D, +1, false, of>(&q[a * D], p2, acc[a], o2[b], false);
       } else if (a == b) {
-        qd_pair<D, 0>(&q[a * D], p1, acc[a], o1[b], late1);
-        qd_pair<D, 0>(&q[a * D], p2, acc[a], o2[b], late2);
+        qd_pair<D, 0, af, of>(&q[a * D], p1, acc[a], o1[b], late1);
+        qd_pair<D, 0, false, of>(&q[a * D], p2, acc[a], o2[b], late2);
       } else {
-        qd_pair<D, -1>(&q[a * D], p1, acc[a], o1[b], true);
+        qd_pair<D, -1, false, of>(&q[a * D], p1, acc[a], o1[b], true);
       }
       // many registers per lane: one pair of tests at a time (the scheduler would interleave the whole row of them)
       if constexpr (R * D > 32) __builtin_amdgcn_sched_barrier(0);
-    }
+      return true;
+    });
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int r = 0; r < NB; ++r) {
-    // what the lane one DOWN found out about my slot r (its "one up" is me), and the lane two up
-    const float v = hk_fmin(acc[r], hk_fmin(qperm<kQuadUp3>(o1[r]), qperm<kQuadUp2>(o2[r])));
-    const bool removed = v <= 0.0f;
+    // what the lane one DOWN found out about my slot r (its "one up" is me), and the lane two up; compares, not a
+    // float minimum of values that came through DPP (those are canonicalised first)
+    const bool r0 = acc[r] <= 0.0f, r1 = qperm<kQuadUp3>(o1[r]) <= 0.0f, r2 = qperm<kQuadUp2>(o2[r]) <= 0.0f;
+    const bool removed = r0 || r1 || r2;
 #pragma unroll
     for (int k = 0; k < D; ++k) q[r * D + k] = removed ? INFINITY : q[r * D + k];
   }

@@ -239,3 +239,59 @@ def gumbel_muzero_policy(params, root_prior_logits, root_value, root_embedding, 
         search_logits = np.where(invalid_actions.astype(bool), F32_MIN, search_logits)
     weights = _softmax64(search_logits).astype(np.float32)
     return PolicyOutput(action.astype(np.int32), weights, tree)
+
+
+# ---- expansion glue (hironaka_amd/csrc/hk_search.h: expand_* / masked_argmax / mask_logits kernels) -------------------
+# What hironaka/jax/recurrent_fn.py does between the search's select and backup, as index arithmetic: 84-104 for a
+# host-role tree (class id -> subset, the agent observation, the agent's masked argmax), 105-121 for an agent-role tree
+# (the host's argmax on the new points, the next agent observation); the agent's action mask is jax/util.py:287-305 in
+# its NaN-free form.  `features` is a second per-node table next to the embeddings (hk_get_features of a node's points).
+def _decode(cls: np.ndarray, dim: int) -> np.ndarray:
+    from .np_oracle import decode_table
+    ncls = 2 ** dim - dim - 1
+    return decode_table(dim)[np.clip(np.asarray(cls), 0, ncls - 1)].astype(np.float32)
+
+
+def _first_argmax_nan_wins(x: np.ndarray) -> np.ndarray:
+    """argmax along the last axis; the first maximum; a NaN beats every number (the first NaN wins)"""
+    x = np.asarray(x)
+    nan = np.isnan(x)
+    return np.where(nan.any(axis=-1), nan.argmax(axis=-1), np.where(nan, -np.inf, x).argmax(axis=-1)).astype(np.int32)
+
+
+def expand_gather(embeddings, features, parent, action, dim):
+    rows = np.arange(embeddings.shape[0])
+    obs = embeddings[rows, parent]
+    agent_feat = np.concatenate([features[rows, parent], _decode(action, dim)], axis=1)
+    return obs, agent_feat
+
+
+def masked_argmax(logits, action, dim):
+    return _first_argmax_nan_wins(np.where(_decode(action, dim) > 0.5, logits, -np.inf))
+
+
+def expand_scatter(obs, feat, node, embeddings, features):
+    rows = np.arange(embeddings.shape[0])
+    embeddings, features = embeddings.copy(), features.copy()
+    embeddings[rows, node] = obs
+    features[rows, node] = feat
+    return embeddings, features
+
+
+def expand_gather_agent(embeddings, parent, dim):
+    rec = embeddings[np.arange(embeddings.shape[0]), parent]
+    return rec[:, :-dim], rec[:, -dim:]
+
+
+def expand_scatter_agent(points, feat, host_logits, node, embeddings, features, dim):
+    rows = np.arange(embeddings.shape[0])
+    cls = _first_argmax_nan_wins(host_logits)
+    mask = _decode(cls, dim)
+    embeddings, features = embeddings.copy(), features.copy()
+    embeddings[rows, node] = np.concatenate([points, mask], axis=1)
+    features[rows, node] = feat
+    return embeddings, features, np.concatenate([feat, mask], axis=1), cls
+
+
+def mask_logits(logits, class_id, dim):
+    return np.where(_decode(class_id, dim) > 0.5, logits, -np.inf).astype(np.float32)

@@ -117,84 +117,68 @@ def test_compute_rho_and_validate():
     assert len(rhos) == 7 and all(len(x) == 8 for x in dets)
 
 
-def test_expand_operators_against_numpy():
-    """hk_search_expand_gather / hk_search_masked_argmax / hk_search_expand_scatter against index arithmetic in numpy
-    (class ids out of range are clamped like hk_decode_host_class; NaN logits win the argmax, first maximum otherwise)"""
-    import ctypes as C
-
+def test_expand_operators_against_oracle():
+    """the search's expansion operators against oracle/search_oracle.py (index arithmetic in numpy): class ids out of
+    range are clamped like hk_decode_host_class; NaN logits win an argmax, the first maximum otherwise"""
     from hironaka_amd._lib import check, lib
-    from hironaka_amd.host_action_preprocess import decode_table
+    from oracle import search_oracle as SO
     L = lib()
     rng = np.random.default_rng(3)
+    dev = lambda a: torch.tensor(a, device="cuda")
+    host = lambda t: t.cpu().numpy()
     for (b, n, m, d) in ((1, 2, 4, 3), (37, 5, 20, 3), (300, 9, 10, 4)):
-        e = m * d
-        emb = torch.tensor(rng.standard_normal((b, n, e)), dtype=torch.float32, device="cuda")
-        feat = torch.tensor(rng.standard_normal((b, n, e)), dtype=torch.float32, device="cuda")
-        parent = torch.tensor(rng.integers(0, n, b), dtype=torch.int32, device="cuda")
-        ncls = 2 ** d - d - 1
-        action = torch.tensor(rng.integers(-1, ncls + 1, b), dtype=torch.int32, device="cuda")
+        e, ncls = m * d, 2 ** d - d - 1
+        f32 = lambda *shape: rng.standard_normal(shape).astype(np.float32)
+        emb, feat = f32(b, n, e), f32(b, n, e)
+        parent = rng.integers(0, n, b).astype(np.int32)
+        node = rng.integers(0, n, b).astype(np.int32)
+        action = rng.integers(-1, ncls + 1, b).astype(np.int32)
+        logits, hl = f32(b, d), f32(b, ncls)
+        for x in (logits, hl):
+            x[rng.random(x.shape) < 0.1] = np.nan
+            x[rng.random(x.shape) < 0.1] = 0.5  # ties
+        o2, f2 = f32(b, e), f32(b, e)
+        # host-role tree
+        g_emb, g_feat, g_par, g_act = dev(emb), dev(feat), dev(parent), dev(action)
         obs = torch.empty((b, e), dtype=torch.float32, device="cuda")
         af = torch.empty((b, e + d), dtype=torch.float32, device="cuda")
-        check(L.hk_search_expand_gather(emb.data_ptr(), feat.data_ptr(), parent.data_ptr(), action.data_ptr(),
+        check(L.hk_search_expand_gather(g_emb.data_ptr(), g_feat.data_ptr(), g_par.data_ptr(), g_act.data_ptr(),
                                         obs.data_ptr(), af.data_ptr(), b, n, m, d, None), "gather")
-        rows = np.arange(b)
-        table = decode_table(d).cpu().numpy().astype(np.float32)
-        masks = table[np.clip(action.cpu().numpy(), 0, ncls - 1)]
-        assert np.array_equal(obs.cpu().numpy(), emb.cpu().numpy()[rows, parent.cpu().numpy()])
-        assert np.array_equal(af.cpu().numpy(),
-                              np.concatenate([feat.cpu().numpy()[rows, parent.cpu().numpy()], masks], axis=1))
-        logits = rng.standard_normal((b, d)).astype(np.float32)
-        logits[rng.random((b, d)) < 0.1] = np.nan
-        logits[rng.random((b, d)) < 0.1] = 0.5  # ties
-        lg = torch.tensor(logits, device="cuda")
+        want_obs, want_af = SO.expand_gather(emb, feat, parent, action, d)
+        assert np.array_equal(host(obs), want_obs) and np.array_equal(host(af), want_af)
+        g_log = dev(logits)
         axis = torch.empty(b, dtype=torch.int32, device="cuda")
-        check(L.hk_search_masked_argmax(lg.data_ptr(), action.data_ptr(), axis.data_ptr(), b, d, None), "argmax")
-        ref = torch.argmax(torch.where(torch.tensor(masks > 0.5), torch.tensor(logits), torch.tensor(-np.inf)), dim=1)
-        assert np.array_equal(axis.cpu().numpy(), ref.numpy().astype(np.int32))
-        node = torch.tensor(rng.integers(0, n, b), dtype=torch.int32, device="cuda")
-        o2 = torch.tensor(rng.standard_normal((b, e)), dtype=torch.float32, device="cuda")
-        f2 = torch.tensor(rng.standard_normal((b, e)), dtype=torch.float32, device="cuda")
-        emb_ref, feat_ref = emb.cpu().numpy().copy(), feat.cpu().numpy().copy()
-        emb_ref[rows, node.cpu().numpy()] = o2.cpu().numpy()
-        feat_ref[rows, node.cpu().numpy()] = f2.cpu().numpy()
-        check(L.hk_search_expand_scatter(o2.data_ptr(), f2.data_ptr(), node.data_ptr(), emb.data_ptr(),
-                                         feat.data_ptr(), b, n, m, d, None), "scatter")
-        assert np.array_equal(emb.cpu().numpy(), emb_ref) and np.array_equal(feat.cpu().numpy(), feat_ref)
-        # the agent-role tree's operators
-        ncl = 2 ** d - d - 1
-        embA = torch.tensor(rng.standard_normal((b, n, e + d)), dtype=torch.float32, device="cuda")
+        check(L.hk_search_masked_argmax(g_log.data_ptr(), g_act.data_ptr(), axis.data_ptr(), b, d, None), "argmax")
+        assert np.array_equal(host(axis), SO.masked_argmax(logits, action, d))
+        g_node, g_o2, g_f2 = dev(node), dev(o2), dev(f2)
+        check(L.hk_search_expand_scatter(g_o2.data_ptr(), g_f2.data_ptr(), g_node.data_ptr(), g_emb.data_ptr(),
+                                         g_feat.data_ptr(), b, n, m, d, None), "scatter")
+        want_emb, want_feat = SO.expand_scatter(o2, f2, node, emb, feat)
+        assert np.array_equal(host(g_emb), want_emb) and np.array_equal(host(g_feat), want_feat)
+        # agent-role tree
+        embA, featA = f32(b, n, e + d), f32(b, n, e)
+        g_embA, g_featA, g_hl = dev(embA), dev(featA), dev(hl)
         pts = torch.empty((b, e), dtype=torch.float32, device="cuda")
         crd = torch.empty((b, d), dtype=torch.float32, device="cuda")
-        check(L.hk_search_expand_gather_agent(embA.data_ptr(), parent.data_ptr(), pts.data_ptr(), crd.data_ptr(),
+        check(L.hk_search_expand_gather_agent(g_embA.data_ptr(), g_par.data_ptr(), pts.data_ptr(), crd.data_ptr(),
                                               b, n, m, d, None), "gather_agent")
-        rec = embA.cpu().numpy()[rows, parent.cpu().numpy()]
-        assert np.array_equal(pts.cpu().numpy(), rec[:, :e]) and np.array_equal(crd.cpu().numpy(), rec[:, e:])
-        hl = rng.standard_normal((b, ncl)).astype(np.float32)
-        hl[rng.random((b, ncl)) < 0.1] = np.nan
-        hl[rng.random((b, ncl)) < 0.1] = 0.25
-        hlg = torch.tensor(hl, device="cuda")
+        want_pts, want_crd = SO.expand_gather_agent(embA, parent, d)
+        assert np.array_equal(host(pts), want_pts) and np.array_equal(host(crd), want_crd)
         afeat = torch.empty((b, e + d), dtype=torch.float32, device="cuda")
         cls = torch.empty(b, dtype=torch.int32, device="cuda")
-        featA = torch.tensor(rng.standard_normal((b, n, e)), dtype=torch.float32, device="cuda")
-        embA_ref, featA_ref = embA.cpu().numpy().copy(), featA.cpu().numpy().copy()
-        check(L.hk_search_expand_scatter_agent(o2.data_ptr(), f2.data_ptr(), hlg.data_ptr(), node.data_ptr(),
-                                               embA.data_ptr(), featA.data_ptr(), afeat.data_ptr(), cls.data_ptr(),
-                                               b, n, m, d, ncl, None), "scatter_agent")
-        cref = torch.argmax(torch.tensor(hl), dim=1).numpy()
-        mref = table[cref]
-        embA_ref[rows, node.cpu().numpy()] = np.concatenate([o2.cpu().numpy(), mref], axis=1)
-        featA_ref[rows, node.cpu().numpy()] = f2.cpu().numpy()
-        assert np.array_equal(cls.cpu().numpy(), cref.astype(np.int32))
-        assert np.array_equal(embA.cpu().numpy(), embA_ref) and np.array_equal(featA.cpu().numpy(), featA_ref)
-        assert np.array_equal(afeat.cpu().numpy(), np.concatenate([f2.cpu().numpy(), mref], axis=1))
-        out = torch.empty_like(lg)
-        check(L.hk_search_mask_logits(lg.data_ptr(), cls.data_ptr(), out.data_ptr(), b, d, None), "mask_logits")
-        want = np.where(mref > 0.5, logits, -np.inf).astype(np.float32)
-        assert np.array_equal(out.cpu().numpy(), want, equal_nan=True)
+        check(L.hk_search_expand_scatter_agent(g_o2.data_ptr(), g_f2.data_ptr(), g_hl.data_ptr(), g_node.data_ptr(),
+                                               g_embA.data_ptr(), g_featA.data_ptr(), afeat.data_ptr(), cls.data_ptr(),
+                                               b, n, m, d, ncls, None), "scatter_agent")
+        want_embA, want_featA, want_afeat, want_cls = SO.expand_scatter_agent(o2, f2, hl, node, embA, featA, d)
+        assert np.array_equal(host(cls), want_cls) and np.array_equal(host(afeat), want_afeat)
+        assert np.array_equal(host(g_embA), want_embA) and np.array_equal(host(g_featA), want_featA)
+        out = torch.empty_like(g_log)
+        check(L.hk_search_mask_logits(g_log.data_ptr(), cls.data_ptr(), out.data_ptr(), b, d, None), "mask_logits")
+        assert np.array_equal(host(out), SO.mask_logits(logits, want_cls, d), equal_nan=True)
     assert L.hk_search_expand_gather(None, None, None, None, None, None, 4, 2, 4, 3, None) == A.HK_ERR_NULL
+    assert L.hk_search_masked_argmax(None, None, None, 4, 1, None) == A.HK_ERR_SHAPE
     assert L.hk_search_expand_scatter_agent(None, None, None, None, None, None, None, None, 4, 2, 4, 3, 9, None) \
         == A.HK_ERR_SHAPE
-    assert L.hk_search_masked_argmax(None, None, None, 4, 1, None) == A.HK_ERR_SHAPE
 
 
 @pytest.mark.parametrize("use_graph", [False, True])

@@ -92,3 +92,29 @@ def test_oracle_search_depth_limit():
                     d += 1
                 assert d <= 2
     assert np.all(t.node_visits[:, 0] == n + 1)
+
+
+def test_expansion_glue_restatement():
+    """oracle/search_oracle.py's expansion glue: the argmax rule equals the tensor library's (first maximum, NaN wins),
+    decode clamps, gather / scatter are inverse on the touched rows"""
+    import torch
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((200, 4)).astype(np.float32)
+    x[rng.random(x.shape) < 0.15] = np.nan
+    x[rng.random(x.shape) < 0.15] = 0.5
+    assert np.array_equal(SO._first_argmax_nan_wins(x), torch.argmax(torch.tensor(x), dim=1).numpy())
+    b, n, m, d = 50, 6, 5, 3
+    e = m * d
+    emb = rng.standard_normal((b, n, e)).astype(np.float32)
+    feat = rng.standard_normal((b, n, e)).astype(np.float32)
+    parent = rng.integers(0, n, b)
+    action = rng.integers(-2, 7, b)
+    obs, af = SO.expand_gather(emb, feat, parent, action, d)
+    assert obs.shape == (b, e) and af.shape == (b, e + d)
+    assert set(np.unique(af[:, e:])) <= {0.0, 1.0} and (af[:, e:].sum(axis=1) >= 2).all()
+    emb2, feat2 = SO.expand_scatter(obs, af[:, :e], parent, emb, feat)
+    assert np.array_equal(emb2, emb) and np.array_equal(feat2, feat)
+    ax = SO.masked_argmax(x[:b, :d], action, d)
+    assert (af[np.arange(b), e + ax] == 1.0).all()
+    ml = SO.mask_logits(x[:b, :d], np.clip(action, 0, 3), d)
+    assert np.isneginf(ml[af[:, e:] == 0.0]).all()
