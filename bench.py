@@ -303,7 +303,7 @@ def main():
         return r
 
     # ---- the one-launch-per-step variants (rank 0's shard, N=1 only) ----------------------------------------------
-    single = api = dense = legal = large = config3 = config5 = None
+    single = api = dense = legal = large = config3 = config5 = overlapped = None
     if extras:
         def episode_stepwise():
             for t in range(EPISODE):
@@ -406,6 +406,34 @@ def main():
                           "hk_step_frac_of_hbm_peak": b * bytes_step * EPISODE / smed / 1e9 / HBM_PEAK_GBS}
         done_count.zero_()
 
+        # ---- two independent episodes in flight (NOT the headline number): the launch of 65 536 games ends with its
+        # slowest waves (mean wave lifetime 15 us inside a 21 us kernel, scripts/probe_timeline.py) and nothing
+        # backfills the SIMDs that are done; episodes are independent (the reference's compute_rho loops are), so a
+        # second stream with its own state buffer fills the tail with the next episode's waves ----------------------
+        state_b = torch.empty_like(fresh)
+        count_ws_b = ops.rollout_workspace(b, EPISODE, (m, d))
+        s2 = torch.cuda.Stream()
+
+        def two_streams():
+            cur = torch.cuda.current_stream()
+            s2.wait_stream(cur)
+            with torch.cuda.stream(s2):
+                for _ in range(BLOCK):
+                    ops.rollout(state_b, EPISODE, SEED + 1, initial=fresh, defer_counts=True, workspace=count_ws_b, **kw)
+            for _ in range(BLOCK):
+                ops.rollout(state, EPISODE, SEED, initial=fresh, defer_counts=True, workspace=count_ws, **kw)
+            cur.wait_stream(s2)
+
+        omed, _, _ = timed_replays(capture(two_streams).replay, MIN_SECTION_S)
+        ops.reduce_counts(count_ws, done_count, b, EPISODE, (m, d))
+        ops.reduce_counts(count_ws_b, done_count, b, EPISODE, (m, d))
+        done_count.zero_()
+        overlapped = {"episodes_in_flight": 2, "us_per_episode": omed / (2 * BLOCK) * 1e6,
+                      "env_steps_per_s": b * EPISODE * 2 * BLOCK / omed,
+                      "note": "secondary: two hipGraph branches (two streams, separate state buffers and count "
+                              "workspaces), each a chain of 65 536-game episodes; `value` above is ONE episode at a time"}
+        del state_b
+
         # ---- same kernels at the batch that saturates one GPU (BASELINE configs[3]'s 524 288 games on ONE
         # device): one lane per game means 65 536 games are only 1024 instruction streams for 1024 SIMDs ----
         bl = 8 * BATCH
@@ -479,26 +507,36 @@ def main():
                "discount": 0.99}
         host_net, host_params = standin_mlp(m * d, 2 ** d - d - 1, 3)
         agent_net, agent_params = standin_mlp(m * d + d, d, 4)
-        trainer = HipTrainer(1, cfg, host_net=host_net, agent_net=agent_net, host_params=host_params,
-                             agent_params=agent_params, use_graph=True)
-        trainer.simulate(0, "host")  # captures one hipGraph per search shape
-        torch.cuda.synchronize()
-        reps, t5 = 3, time.perf_counter()
-        for r in range(reps):
-            obs5, _, _ = trainer.simulate(r + 1, "host")
-        torch.cuda.synchronize()
-        dt5 = (time.perf_counter() - t5) / reps
+        def simulate_seconds(role, fused, reps=3):
+            trainer = HipTrainer(1, cfg, host_net=host_net, agent_net=agent_net, host_params=host_params,
+                                 agent_params=agent_params, use_graph=True, fused_expand=fused)
+            out = trainer.simulate(0, role)  # captures one hipGraph per search shape
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for r in range(reps):
+                out = trainer.simulate(r + 1, role)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps, list(out[0].shape)
+
+        dt5, shape5 = simulate_seconds("host", True)
+        dt5_agent, _ = simulate_seconds("agent", True)
+        dt5_generic, _ = simulate_seconds("host", False, reps=2)
         env5 = cfg["eval_batch_size"] * cfg["num_evaluations"] * EPISODE
         config5 = {"workload": "HipTrainer.simulate(key, 'host'): dim=3, max_points=20, batch=8192, 32 simulations "
                                "per move, 20 moves (BASELINE configs[4]); opponent = the agent network's argmax",
                    "policy_network": "stand-in: fixed random MLPs 60-256-5 / 63-256-4 behind the HIP feature "
                                      "transform (the reference's flax networks are out of scope)",
-                   "launches": "one hipGraph per search (32 simulations), replayed per move",
+                   "launches": "one hipGraph per search (32 simulations), replayed per move; expansions through the "
+                               "fused operators (hk_search_expand_gather / masked_argmax / hk_step / hk_get_features / "
+                               "expand_scatter)",
                    "seconds_per_simulate": dt5, "env_steps_in_search_per_s": env5 / dt5,
-                   "searches_per_s": cfg["eval_batch_size"] * EPISODE / dt5, "samples": list(obs5.shape),
+                   "searches_per_s": cfg["eval_batch_size"] * EPISODE / dt5, "samples": shape5,
+                   "seconds_per_simulate_agent_role": dt5_agent,
+                   "seconds_per_simulate_generic_expansion": dt5_generic,
+                   "generic_expansion_note": "the same call with the expansions as tensor-library glue around hk_step "
+                                             "(HipTrainer(fused_expand=False)): identical rollouts",
                    "hip_kernel_share_of_gpu_time": prof.get("search_hip_kernel_share"),
                    "hip_kernel_share_source": prof_src if prof.get("search_hip_kernel_share") is not None else None}
-        del trainer
 
     if rank == 0:
         launch_s = median_region_s / max(1, launches_per_region)  # per rollout launch (+ its share of the reduce)
@@ -561,7 +599,8 @@ def main():
             "games_finished_per_episode": finished,
         }
         for key, val in (("single_step", single), ("boundary_step", api), ("single_step_dense", dense),
-                         ("large_batch", large), ("legal_axis_torch_list_semantics", legal),
+                         ("overlapped_episodes", overlapped), ("large_batch", large),
+                         ("legal_axis_torch_list_semantics", legal),
                          ("config3_dim4_50points", config3), ("config5_mcts_simulate", config5)):
             if val is not None:
                 out[key] = val

@@ -413,6 +413,11 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   const bool active = gi < ngames;
   const bool leader = active && h == 0;
   const int64_t g = g0 + gi;
+#ifdef HK_DUO_PROBE  // dev builds (scripts/build_probe.sh): a time line per wave, written over game_length_out
+  const long long probe_t0 = wall_clock64();
+  long long probe_t1 = 0, probe_t2 = 0;
+  int probe_steps = 0, probe_smax = 0;
+#endif
   DuoSlabRegs<M, D> slab;
   duo_slab_issue<M, D>(slab, in0, in_stride0, g0, ngames, lane);
   const uint64_t gg = prm.game_offset + (uint64_t)g;
@@ -511,6 +516,10 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
 
   // ---- the pair's rows ----------------------------------------------------------------------------------
   int smax = (nmax + 1) >> 1;
+#ifdef HK_DUO_PROBE
+  probe_t1 = wall_clock64();
+  probe_smax = smax;
+#endif
   float q[CH * D];
 #pragma unroll
   for (int e = 0; e < CH * D; ++e) q[e] = INFINITY;
@@ -589,6 +598,10 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
         ++t;
       }
     });
+#ifdef HK_DUO_PROBE
+    probe_steps = t;
+    probe_t2 = wall_clock64();
+#endif
   }
   const bool want_obs = kRec && prm.obs_out != nullptr;
   const bool want_records = kRec && (prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out);
@@ -675,6 +688,19 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   }
   __syncthreads();
   duo_store_slab<M, D>(lds, (float*)prm.out, prm.out_stride, g0, ngames, lane);
+#ifdef HK_DUO_PROBE
+  if (kRoll && lane == 0 && prm.game_length_out && ngames >= 8) {
+    int32_t* w = prm.game_length_out + g0;
+    w[0] = (int32_t)probe_t0;
+    w[1] = (int32_t)probe_t1;
+    w[2] = (int32_t)probe_t2;
+    w[3] = (int32_t)wall_clock64();
+    w[4] = probe_steps;
+    w[5] = probe_smax;
+    w[6] = (int32_t)blockIdx.x;
+    w[7] = (int32_t)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+  }
+#endif
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------

@@ -1,0 +1,35 @@
+"""Dev probe: per-wave time line of the fused rollout (two-lane kernel, probe build with HK_DUO_PROBE): when each wave
+starts, has its slab, leaves the step loop and ends; how many steps it ran."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hironaka_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build_probe", "libhk_probe.so")
+import numpy as np
+import torch
+from hironaka_amd import ops
+
+b, m, d, T = 65536, 20, 3, 20
+P = ops.generate_points(b, m, d, 20, seed=42)
+Q = torch.empty_like(P)
+for rep in range(3):
+    res = ops.rollout(Q, T, 1 + rep, initial=P, record=("game_length",))
+torch.cuda.synchronize()
+gl = res["game_length"].cpu().numpy().reshape(-1, 32)[:, :8].astype(np.int64)
+t0, t1, t2, t3, steps, smax, blk, hwid = (gl[:, i] for i in range(8))
+base = t0.min()
+us = lambda x: ((x - base) & 0xFFFFFFFF) / 100.0  # 100 MHz constant clock
+print(f"waves {len(t0)}; kernel span (first start .. last end): {us(t3).max():.2f} us")
+for name, v in (("start", us(t0)), ("slab in registers", us(t1)), ("loop done", us(t2)), ("end", us(t3))):
+    print(f"{name:18s} min {v.min():6.2f}  p10 {np.percentile(v,10):6.2f}  median {np.median(v):6.2f}  p90 {np.percentile(v,90):6.2f}  max {v.max():6.2f}")
+life = us(t3) - us(t0)
+print(f"lifetime           mean {life.mean():6.2f}  median {np.median(life):6.2f}  p90 {np.percentile(life,90):6.2f}  max {life.max():6.2f}")
+loop = us(t2) - us(t1)
+print("steps run: " + "  ".join(f"{k}:{(steps==k).sum()}" for k in sorted(set(steps.tolist()))))
+for k in sorted(set(steps.tolist())):
+    sel = steps == k
+    print(f"  steps {k:2d}: waves {sel.sum():5d}  loop time mean {loop[sel].mean():6.2f} us  lifetime mean {life[sel].mean():6.2f}  end max {us(t3)[sel].max():6.2f}")
+print("initial slots per lane: " + "  ".join(f"{k}:{(smax==k).sum()}" for k in sorted(set(smax.tolist()))))
+late = np.argsort(us(t3))[-10:]
+print("the ten last waves: block, start, slab, loop done, end, steps, smax")
+for i in late:
+    print(f"  {blk[i]:5d} {us(t0)[i]:6.2f} {us(t1)[i]:6.2f} {us(t2)[i]:6.2f} {us(t3)[i]:6.2f} {steps[i]:3d} {smax[i]:2d}")
