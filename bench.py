@@ -70,6 +70,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-step", action="store_true", help="headline only (skip every secondary section)")
     ap.add_argument("--no-search", action="store_true", help="skip config5 (MCTS simulate)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="skip the two-episodes-in-flight section (profiling runs: its launches overlap in the trace)")
     return ap.parse_args()
 
 
@@ -410,29 +412,30 @@ def main():
         # slowest waves (mean wave lifetime 15 us inside a 21 us kernel, scripts/probe_timeline.py) and nothing
         # backfills the SIMDs that are done; episodes are independent (the reference's compute_rho loops are), so a
         # second stream with its own state buffer fills the tail with the next episode's waves ----------------------
-        state_b = torch.empty_like(fresh)
-        count_ws_b = ops.rollout_workspace(b, EPISODE, (m, d))
-        s2 = torch.cuda.Stream()
+        if not args.no_overlap:
+            state_b = torch.empty_like(fresh)
+            count_ws_b = ops.rollout_workspace(b, EPISODE, (m, d))
+            s2 = torch.cuda.Stream()
 
-        def two_streams():
-            cur = torch.cuda.current_stream()
-            s2.wait_stream(cur)
-            with torch.cuda.stream(s2):
+            def two_streams():
+                cur = torch.cuda.current_stream()
+                s2.wait_stream(cur)
+                with torch.cuda.stream(s2):
+                    for _ in range(BLOCK):
+                        ops.rollout(state_b, EPISODE, SEED + 1, initial=fresh, defer_counts=True, workspace=count_ws_b, **kw)
                 for _ in range(BLOCK):
-                    ops.rollout(state_b, EPISODE, SEED + 1, initial=fresh, defer_counts=True, workspace=count_ws_b, **kw)
-            for _ in range(BLOCK):
-                ops.rollout(state, EPISODE, SEED, initial=fresh, defer_counts=True, workspace=count_ws, **kw)
-            cur.wait_stream(s2)
+                    ops.rollout(state, EPISODE, SEED, initial=fresh, defer_counts=True, workspace=count_ws, **kw)
+                cur.wait_stream(s2)
 
-        omed, _, _ = timed_replays(capture(two_streams).replay, MIN_SECTION_S)
-        ops.reduce_counts(count_ws, done_count, b, EPISODE, (m, d))
-        ops.reduce_counts(count_ws_b, done_count, b, EPISODE, (m, d))
-        done_count.zero_()
-        overlapped = {"episodes_in_flight": 2, "us_per_episode": omed / (2 * BLOCK) * 1e6,
-                      "env_steps_per_s": b * EPISODE * 2 * BLOCK / omed,
-                      "note": "secondary: two hipGraph branches (two streams, separate state buffers and count "
-                              "workspaces), each a chain of 65 536-game episodes; `value` above is ONE episode at a time"}
-        del state_b
+            omed, _, _ = timed_replays(capture(two_streams).replay, MIN_SECTION_S)
+            ops.reduce_counts(count_ws, done_count, b, EPISODE, (m, d))
+            ops.reduce_counts(count_ws_b, done_count, b, EPISODE, (m, d))
+            done_count.zero_()
+            overlapped = {"episodes_in_flight": 2, "us_per_episode": omed / (2 * BLOCK) * 1e6,
+                          "env_steps_per_s": b * EPISODE * 2 * BLOCK / omed,
+                          "note": "secondary: two hipGraph branches (two streams, separate state buffers and count "
+                                  "workspaces), each a chain of 65 536-game episodes; `value` above is ONE episode at a time"}
+            del state_b
 
         # ---- same kernels at the batch that saturates one GPU (BASELINE configs[3]'s 524 288 games on ONE
         # device): one lane per game means 65 536 games are only 1024 instruction streams for 1024 SIMDs ----

@@ -36,6 +36,14 @@
  *   hk_get_features          jax/util.py:172-214 get_feature_fn (order_and_rescale)
  *   hk_get_features_torch    core/tensor_points.py:72-74 TensorPoints.get_features
  *   hk_decode_host_class     jax/host_action_preprocess.py:8-65, src/_fn.py:241-325
+ *   hk_search_select / _backup / _policy
+ *                            the calls into mctx at jax/simulation_fn.py:85-117
+ *   hk_search_expand_gather / _masked_argmax / _expand_scatter
+ *                            jax/recurrent_fn.py:84-104 (host-role tree: class id -> subset,
+ *                            agent observation, the agent's masked argmax, the new embedding)
+ *   hk_search_expand_gather_agent / _expand_scatter_agent / _mask_logits
+ *                            jax/recurrent_fn.py:105-121 (agent-role tree) and the agent's
+ *                            action mask jax/util.py:287-305
  */
 #ifndef HIRONAKA_HIP_H
 #define HIRONAKA_HIP_H
