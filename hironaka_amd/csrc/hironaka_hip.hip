@@ -556,6 +556,18 @@ int hk_search_mask_logits(const void* logits, const int32_t* class_id, void* out
   return launch_mask_logits((const float*)logits, class_id, (float*)out, batch, dim, (hipStream_t)stream);
 }
 
+int hk_rollout_values(const void* obs, void* value_out, int batch, int steps, int obs_dim, int dim,
+                      int points_offset, float discount, float reward_sign, float estimate_scale, void* stream) {
+  if (batch < 0 || steps < 1 || obs_dim < 1 || dim < 1 || dim > kMaxDim || points_offset < 0 || points_offset > 1)
+    return HK_ERR_SHAPE;
+  if (steps > 64) return HK_ERR_UNSUPPORTED;
+  if (batch == 0) return HK_OK;
+  if (!obs || !value_out) return HK_ERR_NULL;
+  if (!aligned(obs, 4) || !aligned(value_out, 4)) return HK_ERR_ALIGN;
+  return launch_rollout_values((const float*)obs, (float*)value_out, batch, steps, obs_dim, dim, points_offset, discount,
+                               reward_sign, estimate_scale, (hipStream_t)stream);
+}
+
 int hk_zeillinger(const void* points, int64_t stride, int32_t* class_out, int batch,
                   int max_points, int dim, int dtype, uint32_t flags, void* stream) {
   int st = check_spec(batch, max_points, dim, dtype);

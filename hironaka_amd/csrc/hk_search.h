@@ -581,4 +581,47 @@ inline int launch_expand_scatter(const float* obs, const float* feat_in, const i
   return launch_status();
 }
 
+// ---- value targets of a finished self-play rollout: JAXTrainer.rollout_postprocess (jax_trainer.py:558-592) ->
+// calculate_value_using_reward_fn (jax/util.py:261-284).  obs [B, T, obs_dim]: the observation before each move;
+// num_points[t] = #(entries >= 0) / dim - offset; done = num_points <= 1; a move that finishes the game earns
+// rew_sign; value[t] = sum_s rew[s] * clip(disc^(s - t), -1, 1)  (the discounted reward of the finishing move; constant
+// after the end through the clip)  +  [game unfinished at T-1] est_scale / max(num_points[T-1], 1) * disc^(T-1-t).
+// One wave per game, lane t = move t (T <= 64).
+__global__ __launch_bounds__(64) void rollout_values_kernel(const float* obs, float* value_out, int batch, int T,
+                                                            int obs_dim, int dim, int offset, float disc,
+                                                            float rew_sign, float est_scale) {
+  const int b = blockIdx.x;
+  const int t = threadIdx.x;
+  if (b >= batch) return;
+  int np = 2;
+  if (t < T) {
+    const float* row = obs + ((int64_t)b * T + t) * obs_dim;
+    int count = 0;
+    for (int e = 0; e < obs_dim; ++e) count += (row[e] >= 0.0f) ? 1 : 0;
+    np = count / dim - offset;
+  }
+  const bool done = np <= 1;
+  const bool next_done = __shfl_down(done ? 1 : 0, 1) != 0 && t + 1 < T;
+  const bool rew = t < T && next_done && !done;
+  unsigned long long finishing = __ballot(rew);
+  const int np_last = __shfl(np, T - 1);
+  float acc = 0.0f;
+  while (finishing) {  // (ascending s: the order of a row-times-table product's non-zero terms)
+    const int s = __ffsll((long long)finishing) - 1;
+    finishing &= finishing - 1;
+    acc += rew_sign * fminf(fmaxf(powf(disc, (float)(s - t)), -1.0f), 1.0f);
+  }
+  const float unfinished = (np_last <= 1) ? 0.0f
+                                          : est_scale / (float)(np_last < 1 ? 1 : np_last) * powf(disc, (float)(T - 1 - t));
+  if (t < T) value_out[(int64_t)b * T + t] = acc + unfinished;
+}
+
+inline int launch_rollout_values(const float* obs, float* value_out, int batch, int T, int obs_dim, int dim, int offset,
+                                 float disc, float rew_sign, float est_scale, hipStream_t stream) {
+  launch_prepare();
+  hipLaunchKernelGGL(rollout_values_kernel, dim3(batch), dim3(64), 0, stream, obs, value_out, batch, T, obs_dim, dim,
+                     offset, disc, rew_sign, est_scale);
+  return launch_status();
+}
+
 }  // namespace hk

@@ -197,8 +197,27 @@ def rollout_postprocess(rollouts, role: str, dimension: int, discount: float = 0
     [B*T, A], [B*T])."""
     obs, policy, value = rollouts
     offset = 1 if (use_unified_tree or role == "agent") else 0
-    num_points = (obs >= 0).sum(dim=-1) // dimension - offset
-    new_value = calculate_value_using_reward_fn(num_points, discount, role, use_unified_tree).to(value.dtype)
+    b, t, width = obs.shape
+    if obs.is_cuda and obs.dtype == torch.float32 and t <= 64:
+        # one launch (hk_rollout_values: a wave per game) instead of ~15 tensor-library launches
+        if role not in ("host", "agent"):
+            raise ValueError(f"role must be either host or agent. Got {role}.")
+        import ctypes as C
+
+        from ._lib import check, lib
+        o = obs.contiguous()
+        out = torch.empty((b, t), dtype=torch.float32, device=obs.device)
+        agent_like = use_unified_tree or role == "agent"
+        est = (1.0 if role == "host" else -1.0) * ((-1.0) ** (t + 1) if use_unified_tree else 1.0)
+        with torch.cuda.device(obs.device):
+            check(lib().hk_rollout_values(o.data_ptr(), out.data_ptr(), b, t, width, dimension, offset,
+                                          -discount if use_unified_tree else discount, -1.0 if agent_like else 1.0,
+                                          est, C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)),
+                  "hk_rollout_values")
+        new_value = out.to(value.dtype)
+    else:
+        num_points = (obs >= 0).sum(dim=-1) // dimension - offset
+        new_value = calculate_value_using_reward_fn(num_points, discount, role, use_unified_tree).to(value.dtype)
     return obs.reshape(-1, obs.shape[2]), policy.reshape(-1, policy.shape[2]), new_value.reshape(-1)
 
 

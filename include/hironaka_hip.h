@@ -36,6 +36,7 @@
  *   hk_get_features          jax/util.py:172-214 get_feature_fn (order_and_rescale)
  *   hk_get_features_torch    core/tensor_points.py:72-74 TensorPoints.get_features
  *   hk_decode_host_class     jax/host_action_preprocess.py:8-65, src/_fn.py:241-325
+ *   hk_rollout_values        jax/jax_trainer.py:558-592 rollout_postprocess, jax/util.py:261-284
  *   hk_search_select / _backup / _policy
  *                            the calls into mctx at jax/simulation_fn.py:85-117
  *   hk_search_expand_gather / _masked_argmax / _expand_scatter
@@ -313,6 +314,16 @@ int hk_search_expand_scatter_agent(const void* points, const void* feat, const v
 /* out[b, k] = logits[b, k] if coordinate k belongs to the subset of class_id[b], else -inf (the agent's action
  * mask, jax/util.py:287-305 in its NaN-free form); out may equal logits                                       */
 int hk_search_mask_logits(const void* logits, const int32_t* class_id, void* out, int batch, int dim, void* stream);
+
+/* ---- value targets of a self-play rollout: JAXTrainer.rollout_postprocess (jax_trainer.py:558-592) with
+ * calculate_value_using_reward_fn (jax/util.py:261-284) ----------------------------------------------------------
+ * obs [B, T, obs_dim] float32 (the observation before each of the T moves; T <= 64), value_out [B, T] float32.
+ * num_points = #(entries >= 0) / dim - points_offset (1 when the observation carries the subset tail: agent role /
+ * unified tree); discount is signed (the unified tree passes -discount); reward_sign = +1 host, -1 agent / unified;
+ * estimate_scale = the sign of the "1 / remaining points" estimate of an unfinished game (+1 host, -1 agent,
+ * times (-1)^(T+1) on a unified tree).                                                                            */
+int hk_rollout_values(const void* obs, void* value_out, int batch, int steps, int obs_dim, int dim,
+                      int points_offset, float discount, float reward_sign, float estimate_scale, void* stream);
 
 /* ---- fixed host policy as its own operator: class id per game -------------------------- */
 /* flags: HK_SEM_JAX (default; all ordered pairs, isclose-degenerate pairs skipped, degenerate

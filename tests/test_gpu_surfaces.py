@@ -631,3 +631,30 @@ def test_policy_players():
         assert torch.equal(a.state.points, b.state.points)
     assert len(a.move_history) == len(b.move_history) > 0
     assert torch.equal(a.coord_history[0], b.coord_history[0]) and torch.equal(a.move_history[0], b.move_history[0])
+
+
+def test_rollout_values_kernel_random_patterns():
+    """hk_rollout_values (the device path of rollout_postprocess) against the oracle's restatement of
+    jax_trainer.py:558-592 / jax/util.py:261-284 on random observation patterns -- also ones no game produces (point
+    counts that go up again: several finishing moves in one row), every role / tree kind, T = 1 .. 64"""
+    rng = np.random.default_rng(11)
+    d = 3
+    for T in (1, 2, 5, 20, 33, 64):
+        for role, unified, width in (("host", False, 60), ("agent", False, 63), ("host", True, 63), ("agent", True, 63)):
+            b = 97
+            obs = np.full((b, T, width), -1.0, dtype=np.float32)
+            for i in range(b):
+                monotone = rng.random() < 0.7
+                n = int(rng.integers(1, 8))
+                for t in range(T):
+                    if monotone:
+                        n = max(int(n - rng.integers(0, 2)), 0)
+                    else:
+                        n = int(rng.integers(0, 6))
+                    k = n + (1 if width == 63 else 0)
+                    obs[i, t, : k * d] = rng.integers(0, 5, k * d)
+            rollouts = (dev(obs), torch.zeros(b, T, 4, device="cuda"), torch.zeros(b, T, device="cuda"))
+            _, _, v = rollout_postprocess(rollouts, role, d, 0.99, unified)
+            want = NO.rollout_postprocess(obs, d, 0.99, role, use_unified_tree=unified)
+            # (rows with many finishing moves sum tens of terms: float32 accumulation order shows in the last bits)
+            assert np.allclose(host(v), want, rtol=2e-6, atol=2e-6), (T, role, unified, np.abs(host(v) - want).max())
