@@ -403,10 +403,10 @@ inline int launch_search_policy(const SearchTree& t, const float* gumbel, const 
 // the host's class id (host_action_preprocess: class -> mask, out-of-range ids clamped like hk_decode_host_class)
 __global__ void expand_gather_kernel(const float* emb, const float* feat, const int32_t* parent, const int32_t* action,
                                      float* obs_out, float* agent_feat_out, int batch, int nodes, int E, int d) {
+  // (blockIdx.x = the game, blockIdx.y = chunk of its row: no division of a 64-bit linear index by a run-time length)
   const int per = 2 * E + d;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)batch * per) return;
-  const int g = (int)(idx / per), e = (int)(idx % per);
+  const int g = blockIdx.x, e = blockIdx.y * blockDim.x + threadIdx.x;
+  if (e >= per) return;
   int p = parent[g];
   p = p < 0 ? 0 : (p >= nodes ? nodes - 1 : p);
   const int64_t row = ((int64_t)g * nodes + p) * E;
@@ -447,9 +447,8 @@ __global__ void masked_argmax_kernel(const float* logits, const int32_t* action,
 // embeddings[b, node[b]] = obs[b];  features[b, node[b]] = feat[b]
 __global__ void expand_scatter_kernel(const float* obs, const float* feat_in, const int32_t* node, float* emb,
                                       float* feat, int batch, int nodes, int E) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)batch * 2 * E) return;
-  const int g = (int)(idx / (2 * E)), e = (int)(idx % (2 * E));
+  const int g = blockIdx.x, e = blockIdx.y * blockDim.x + threadIdx.x;
+  if (e >= 2 * E) return;
   const int n = node[g];
   if (n < 0 || n >= nodes) return;
   const int64_t row = ((int64_t)g * nodes + n) * E;
@@ -463,9 +462,8 @@ __global__ void expand_scatter_kernel(const float* obs, const float* feat_in, co
 __global__ void expand_gather_agent_kernel(const float* emb, const int32_t* parent, float* points_out,
                                            float* coords_out, int batch, int nodes, int E, int d) {
   const int per = E + d;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)batch * per) return;
-  const int g = (int)(idx / per), e = (int)(idx % per);
+  const int g = blockIdx.x, e = blockIdx.y * blockDim.x + threadIdx.x;
+  if (e >= per) return;
   int p = parent[g];
   p = p < 0 ? 0 : (p >= nodes ? nodes - 1 : p);
   const float v = emb[((int64_t)g * nodes + p) * per + e];
@@ -480,9 +478,8 @@ __global__ void expand_scatter_agent_kernel(const float* points, const float* fe
                                             const int32_t* node, float* emb, float* feat, float* agent_feat_out,
                                             int32_t* class_out, int batch, int nodes, int E, int d, int C) {
   const int per = 2 * E + d;  // E points, E features, d mask entries
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)batch * per) return;
-  const int g = (int)(idx / per), e = (int)(idx % per);
+  const int g = blockIdx.x, e = blockIdx.y * blockDim.x + threadIdx.x;
+  if (e >= per) return;
   const int n = node[g];
   const bool inside = n >= 0 && n < nodes;
   const int64_t erow = ((int64_t)g * nodes + (inside ? n : 0)) * (E + d);
@@ -525,11 +522,14 @@ __global__ void mask_logits_kernel(const float* logits, const int32_t* class_id,
   out[idx] = ((decode_class(c, d) >> k) & 1u) ? logits[idx] : -INFINITY;
 }
 
+// the glue kernels' grid: x = the games, y = 128-element chunks of one game's row of work
+constexpr int kExpandBlock = 128;
+inline dim3 expand_grid(int per, int batch) { return dim3((unsigned)batch, (unsigned)((per + kExpandBlock - 1) / kExpandBlock)); }
+
 inline int launch_expand_gather_agent(const float* emb, const int32_t* parent, float* points_out, float* coords_out,
                                       int batch, int nodes, int E, int d, hipStream_t stream) {
   launch_prepare();
-  const int64_t total = (int64_t)batch * (E + d);
-  hipLaunchKernelGGL(expand_gather_agent_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, emb,
+  hipLaunchKernelGGL(expand_gather_agent_kernel, expand_grid(E + d, batch), dim3(kExpandBlock), 0, stream, emb,
                      parent, points_out, coords_out, batch, nodes, E, d);
   return launch_status();
 }
@@ -539,8 +539,7 @@ inline int launch_expand_scatter_agent(const float* points, const float* feat_in
                                        int32_t* class_out, int batch, int nodes, int E, int d, int C,
                                        hipStream_t stream) {
   launch_prepare();
-  const int64_t total = (int64_t)batch * (2 * E + d);
-  hipLaunchKernelGGL(expand_scatter_agent_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, points,
+  hipLaunchKernelGGL(expand_scatter_agent_kernel, expand_grid(2 * E + d, batch), dim3(kExpandBlock), 0, stream, points,
                      feat_in, host_logits, node, emb, feat, agent_feat_out, class_out, batch, nodes, E, d, C);
   return launch_status();
 }
@@ -558,8 +557,7 @@ inline int launch_expand_gather(const float* emb, const float* feat, const int32
                                 float* obs_out, float* agent_feat_out, int batch, int nodes, int E, int d,
                                 hipStream_t stream) {
   launch_prepare();
-  const int64_t total = (int64_t)batch * (2 * E + d);
-  hipLaunchKernelGGL(expand_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, emb, feat,
+  hipLaunchKernelGGL(expand_gather_kernel, expand_grid(2 * E + d, batch), dim3(kExpandBlock), 0, stream, emb, feat,
                      parent, action, obs_out, agent_feat_out, batch, nodes, E, d);
   return launch_status();
 }
@@ -575,8 +573,7 @@ inline int launch_masked_argmax(const float* logits, const int32_t* action, int3
 inline int launch_expand_scatter(const float* obs, const float* feat_in, const int32_t* node, float* emb, float* feat,
                                  int batch, int nodes, int E, hipStream_t stream) {
   launch_prepare();
-  const int64_t total = (int64_t)batch * 2 * E;
-  hipLaunchKernelGGL(expand_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, obs, feat_in,
+  hipLaunchKernelGGL(expand_scatter_kernel, expand_grid(2 * E, batch), dim3(kExpandBlock), 0, stream, obs, feat_in,
                      node, emb, feat, batch, nodes, E);
   return launch_status();
 }
