@@ -486,16 +486,20 @@ static int expand_shape_ok(int batch, int num_nodes, int max_points, int dim) {
 
 int hk_search_expand_gather(const void* embeddings, const void* features, const int32_t* parent,
                             const int32_t* action, void* obs_out, void* agent_feat_out, int batch,
-                            int num_nodes, int max_points, int dim, void* stream) {
+                            int num_nodes, int max_points, int dim, int node_major, void* stream) {
   const int st = expand_shape_ok(batch, num_nodes, max_points, dim);
   if (st != HK_OK) return st;
+  const int64_t E64 = (int64_t)max_points * dim;
+  const int64_t game_stride = node_major ? E64 : (int64_t)num_nodes * E64;
+  const int64_t node_stride = node_major ? (int64_t)batch * E64 : E64;
   if (batch == 0) return HK_OK;
   if (!embeddings || !features || !parent || !action || !obs_out || !agent_feat_out) return HK_ERR_NULL;
   if (!aligned(embeddings, 4) || !aligned(features, 4) || !aligned(parent, 4) || !aligned(action, 4) ||
       !aligned(obs_out, 4) || !aligned(agent_feat_out, 4))
     return HK_ERR_ALIGN;
   return launch_expand_gather((const float*)embeddings, (const float*)features, parent, action, (float*)obs_out,
-                              (float*)agent_feat_out, batch, num_nodes, max_points * dim, dim, (hipStream_t)stream);
+                              (float*)agent_feat_out, batch, num_nodes, max_points * dim, dim, game_stride, node_stride,
+                              (hipStream_t)stream);
 }
 
 int hk_search_masked_argmax(const void* logits, const int32_t* action, int32_t* axis_out, int batch, int dim,

@@ -401,15 +401,17 @@ inline int launch_search_policy(const SearchTree& t, const float* gumbel, const 
 
 // obs_out [B, E] = embeddings[b, parent[b]];  agent_feat_out [B, E + d] = features[b, parent[b]] ++ the 0/1 subset of
 // the host's class id (host_action_preprocess: class -> mask, out-of-range ids clamped like hk_decode_host_class)
+// (game_stride / node_stride, in elements: [B, N, E] tables pass N * E and E, node-major [N, B, E] ones E and B * E)
 __global__ void expand_gather_kernel(const float* emb, const float* feat, const int32_t* parent, const int32_t* action,
-                                     float* obs_out, float* agent_feat_out, int batch, int nodes, int E, int d) {
+                                     float* obs_out, float* agent_feat_out, int batch, int nodes, int E, int d,
+                                     int64_t game_stride, int64_t node_stride) {
   // (blockIdx.x = the game, blockIdx.y = chunk of its row: no division of a 64-bit linear index by a run-time length)
   const int per = 2 * E + d;
   const int g = blockIdx.x, e = blockIdx.y * blockDim.x + threadIdx.x;
   if (e >= per) return;
   int p = parent[g];
   p = p < 0 ? 0 : (p >= nodes ? nodes - 1 : p);
-  const int64_t row = ((int64_t)g * nodes + p) * E;
+  const int64_t row = (int64_t)g * game_stride + (int64_t)p * node_stride;
   if (e < E) {
     obs_out[(int64_t)g * E + e] = emb[row + e];
   } else if (e < 2 * E) {
@@ -555,10 +557,10 @@ inline int launch_mask_logits(const float* logits, const int32_t* class_id, floa
 
 inline int launch_expand_gather(const float* emb, const float* feat, const int32_t* parent, const int32_t* action,
                                 float* obs_out, float* agent_feat_out, int batch, int nodes, int E, int d,
-                                hipStream_t stream) {
+                                int64_t game_stride, int64_t node_stride, hipStream_t stream) {
   launch_prepare();
   hipLaunchKernelGGL(expand_gather_kernel, expand_grid(2 * E + d, batch), dim3(kExpandBlock), 0, stream, emb, feat,
-                     parent, action, obs_out, agent_feat_out, batch, nodes, E, d);
+                     parent, action, obs_out, agent_feat_out, batch, nodes, E, d, game_stride, node_stride);
   return launch_status();
 }
 

@@ -280,7 +280,7 @@ def zeillinger(points: torch.Tensor, sem: str = "jax", spec=None, force_generic:
 
 
 def get_features(points: torch.Tensor, scale_observation: bool = True, padding_value: float = -1.0,
-                 spec=None) -> torch.Tensor:
+                 spec=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """order_and_rescale (jax/util.py:186-197): [B, m*d] rows sorted descending, last coordinate
     primary, optionally rescaled first."""
     pts, orig = _state(points)
@@ -292,7 +292,10 @@ def get_features(points: torch.Tensor, scale_observation: bool = True, padding_v
         m, d = spec
     else:
         raise ValueError("points must be [B, m, d], or [B, stride] together with spec=(m, d)")
-    out = torch.empty((b, m * d), dtype=pts.dtype, device=pts.device)
+    if out is None:
+        out = torch.empty((b, m * d), dtype=pts.dtype, device=pts.device)
+    elif (not out.is_cuda or out.dtype != pts.dtype or tuple(out.shape) != (b, m * d) or not out.is_contiguous()):
+        raise ValueError(f"out must be a contiguous [{b}, {m * d}] {pts.dtype} tensor on the device")
     with torch.cuda.device(pts.device):
         check(lib().hk_get_features(pts.data_ptr(), in_stride, out.data_ptr(), m * d, b, m, d,
                                     _TORCH2HK[pts.dtype], int(bool(scale_observation)), float(padding_value),

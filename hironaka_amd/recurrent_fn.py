@@ -30,8 +30,8 @@ class HostExpander:
     """One expansion of a HOST-role tree as fused device work (recurrent_fn.py:84-104 around the two networks):
 
         hk_search_expand_gather  (parent points + parent features ++ subset of the host's class id)
-        -> agent network -> hk_search_masked_argmax -> hk_step (class ids, int32 axis) -> hk_get_features
-        -> hk_search_expand_scatter (points and features of the new node) -> host network
+        -> agent network -> hk_search_masked_argmax -> hk_step (class ids, int32 axis; writes the new node's points)
+        -> hk_get_features (writes the new node's features) -> host network
 
     instead of gather / decode / concat / feature sort of the strided agent observation / concat / mask fill /
     compare / where / argmax / step / feature sort / index_put.  It needs the two networks as
@@ -55,13 +55,20 @@ class HostExpander:
                 and root_embedding.shape[1] == self.m * self.d)
 
     def begin(self, tree, root_embedding: torch.Tensor):
-        """per search: the feature table (root row filled) and the scratch arrays of an expansion"""
+        """per search: the two node-major tables [N, B, E] (points and features; root rows filled) and the scratch
+        arrays of an expansion.  Simulation s creates node s + 1, so the step and the feature transform write the new
+        rows straight into slice s + 1 -- no scatter.  (A game whose descent stopped on an existing child, at the depth
+        limit, re-derives that child's rows: identical values, and its slot s + 1 is never referenced.)
+        `state["tree"]` is the tree with `embeddings` replaced by the [B, N, E] view of the points table."""
         from . import ops
         b, n, e = tree.embeddings.shape
         dev = tree.embeddings.device
-        features = torch.zeros((b, n, e), dtype=torch.float32, device=dev)
-        features[:, 0] = ops.get_features(root_embedding.contiguous(), self.scale_observation, spec=(self.m, self.d))
-        return {"features": features,
+        points = torch.zeros((n, b, e), dtype=torch.float32, device=dev)
+        features = torch.zeros((n, b, e), dtype=torch.float32, device=dev)
+        points[0] = root_embedding
+        ops.get_features(root_embedding.contiguous(), self.scale_observation, spec=(self.m, self.d), out=features[0])
+        return {"tree": tree._replace(embeddings=points.permute(1, 0, 2)), "points": points, "features": features,
+                "sim": 0,
                 "obs": torch.empty((b, e), dtype=torch.float32, device=dev),
                 "agent_feat": torch.empty((b, e + self.d), dtype=torch.float32, device=dev),
                 "axis": torch.empty(b, dtype=torch.int32, device=dev),
@@ -73,25 +80,24 @@ class HostExpander:
         from . import ops
         from ._lib import check, lib
         (host_params, *_), (agent_params, *_) = params
-        b, n, e = tree.embeddings.shape
+        points, features = state["points"], state["features"]
+        n, b, e = points.shape
         m, d = self.m, self.d
         L = lib()
-        stream = C.c_void_p(torch.cuda.current_stream(tree.embeddings.device).cuda_stream)
-        obs, agent_feat, axis, features = state["obs"], state["agent_feat"], state["axis"], state["features"]
-        check(L.hk_search_expand_gather(tree.embeddings.data_ptr(), features.data_ptr(), parent.data_ptr(),
-                                        action.data_ptr(), obs.data_ptr(), agent_feat.data_ptr(), b, n, m, d, stream),
+        stream = C.c_void_p(torch.cuda.current_stream(points.device).cuda_stream)
+        obs, agent_feat, axis = state["obs"], state["agent_feat"], state["axis"]
+        slot = state["sim"] + 1  # the node this simulation creates (hk_search_select's next_free_node)
+        state["sim"] += 1
+        check(L.hk_search_expand_gather(points.data_ptr(), features.data_ptr(), parent.data_ptr(), action.data_ptr(),
+                                        obs.data_ptr(), agent_feat.data_ptr(), b, n, m, d, 1, stream),
               "hk_search_expand_gather")
         logits, _ = self.agent_model(agent_feat, agent_params)
         logits = logits.to(torch.float32).contiguous()
         check(L.hk_search_masked_argmax(logits.data_ptr(), action.data_ptr(), axis.data_ptr(), b, d, stream),
               "hk_search_masked_argmax")
-        res = ops.step(obs, action, axis, stages=self.stages, spec=(m, d), want=("done", "prev_done", "reward"),
-                       reward_sign=self.reward_sign)
-        nxt = res["points"].reshape(b, e)
-        host_feat = ops.get_features(nxt, self.scale_observation, spec=(m, d))
-        check(L.hk_search_expand_scatter(nxt.data_ptr(), host_feat.data_ptr(), node.data_ptr(),
-                                         tree.embeddings.data_ptr(), features.data_ptr(), b, n, m, d, stream),
-              "hk_search_expand_scatter")
+        res = ops.step(obs, action, axis, stages=self.stages, spec=(m, d), out=points[slot],
+                       want=("done", "prev_done", "reward"), reward_sign=self.reward_sign)
+        host_feat = ops.get_features(points[slot], self.scale_observation, spec=(m, d), out=features[slot])
         prior, value = self.host_model(host_feat, host_params)
         return RecurrentFnOutput(reward=res["reward"], discount=state["discount"], prior_logits=prior,
                                  value=value.reshape(b))

@@ -159,6 +159,8 @@ def _run_search(params, rng_key, root: RootFnOutput, gumbel: torch.Tensor, inval
         expander = None
     with torch.cuda.device(dev):
         expand_state = expander.begin(tree, root.embedding) if expander is not None else None
+        if expand_state is not None and "tree" in expand_state:
+            tree = expand_state["tree"]  # (an expander may keep the embeddings in its own layout: same fields, a view)
         for sim in range(num_simulations):
             check(L.hk_search_select(C.byref(desc), gumbel.data_ptr(), inv_ptr, table.data_ptr(),
                                      max_num_considered_actions, num_simulations, max_depth, sim + 1,

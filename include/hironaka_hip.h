@@ -283,12 +283,16 @@ int hk_search_policy(const hk_search_tree* tree, const float* root_gumbel, const
  * The caller keeps two tables per tree: embeddings [B, N, E] (the points of every node, E = max_points*dim,
  * float32) and features [B, N, E] (hk_get_features of those points, written once when a node is created).
  * One expansion = hk_search_expand_gather -> agent network on agent_feat_out -> hk_search_masked_argmax ->
- * hk_step (class-id coords, int32 axis) -> hk_get_features -> hk_search_expand_scatter -> host network. */
+ * hk_step (class-id coords, int32 axis) -> hk_get_features -> hk_search_expand_scatter -> host network.
+ * node_major != 0: the two tables are laid out [N, B, E] instead -- simulation s creates node s + 1 for every game
+ * that expands an unvisited edge, so hk_step / hk_get_features can write the new rows straight into slice s + 1 of
+ * the tables (a game whose descent stopped on an existing child re-derives that child's rows, and its slot s + 1 is
+ * never referenced) and hk_search_expand_scatter is not needed.                                               */
 /* obs_out [B, E] = embeddings[b, parent[b]]; agent_feat_out [B, E + dim] = features[b, parent[b]] followed by
  * the 0/1 subset of the host's class id action[b] (clamped into range like hk_decode_host_class)           */
 int hk_search_expand_gather(const void* embeddings, const void* features, const int32_t* parent,
                             const int32_t* action, void* obs_out, void* agent_feat_out, int batch,
-                            int num_nodes, int max_points, int dim, void* stream);
+                            int num_nodes, int max_points, int dim, int node_major, void* stream);
 /* axis_out[b] = argmax_k of logits[b, k] over the coordinates k of the subset of class id action[b]
  * (jax/util.py:287-327: the agent's action mask + argmax; first maximum, NaN beats every number)       */
 int hk_search_masked_argmax(const void* logits, const int32_t* action, int32_t* axis_out, int batch, int dim,

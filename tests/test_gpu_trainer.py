@@ -143,8 +143,14 @@ def test_expand_operators_against_oracle():
         obs = torch.empty((b, e), dtype=torch.float32, device="cuda")
         af = torch.empty((b, e + d), dtype=torch.float32, device="cuda")
         check(L.hk_search_expand_gather(g_emb.data_ptr(), g_feat.data_ptr(), g_par.data_ptr(), g_act.data_ptr(),
-                                        obs.data_ptr(), af.data_ptr(), b, n, m, d, None), "gather")
+                                        obs.data_ptr(), af.data_ptr(), b, n, m, d, 0, None), "gather")
         want_obs, want_af = SO.expand_gather(emb, feat, parent, action, d)
+        assert np.array_equal(host(obs), want_obs) and np.array_equal(host(af), want_af)
+        # the same tables laid out node-major [N, B, E]
+        nm_emb, nm_feat = dev(np.ascontiguousarray(emb.transpose(1, 0, 2))), dev(np.ascontiguousarray(feat.transpose(1, 0, 2)))
+        obs.zero_(), af.zero_()
+        check(L.hk_search_expand_gather(nm_emb.data_ptr(), nm_feat.data_ptr(), g_par.data_ptr(), g_act.data_ptr(),
+                                        obs.data_ptr(), af.data_ptr(), b, n, m, d, 1, None), "gather node-major")
         assert np.array_equal(host(obs), want_obs) and np.array_equal(host(af), want_af)
         g_log = dev(logits)
         axis = torch.empty(b, dtype=torch.int32, device="cuda")
@@ -175,7 +181,7 @@ def test_expand_operators_against_oracle():
         out = torch.empty_like(g_log)
         check(L.hk_search_mask_logits(g_log.data_ptr(), cls.data_ptr(), out.data_ptr(), b, d, None), "mask_logits")
         assert np.array_equal(host(out), SO.mask_logits(logits, want_cls, d), equal_nan=True)
-    assert L.hk_search_expand_gather(None, None, None, None, None, None, 4, 2, 4, 3, None) == A.HK_ERR_NULL
+    assert L.hk_search_expand_gather(None, None, None, None, None, None, 4, 2, 4, 3, 0, None) == A.HK_ERR_NULL
     assert L.hk_search_masked_argmax(None, None, None, 4, 1, None) == A.HK_ERR_SHAPE
     assert L.hk_search_expand_scatter_agent(None, None, None, None, None, None, None, None, 4, 2, 4, 3, 9, None) \
         == A.HK_ERR_SHAPE
