@@ -23,6 +23,7 @@ HK_F32, HK_F64, HK_I32, HK_I64, HK_U8 = 0, 1, 2, 3, 4
 HK_COORDS_CLASS_I32 = 16
 HK_COORDS_CLASS_I64 = 17
 HK_COORDS_IN_RECORD = 18
+HK_AXIS_MASKED_LOGITS = 32
 HK_COORDS_NONE = 19
 
 # stages

@@ -84,6 +84,8 @@ int launch(Params& prm, int dtype, hipStream_t stream) {
     prm.flags &= ~kHostSideFlags;
     return launch_quad(prm, stream);
   }
+  // (the agent's move as an argmax of its logits is decoded by the four-lane kernel only)
+  if ((prm.stages & HK_STAGE_SHIFT) && prm.axis_dtype == HK_AXIS_MASKED_LOGITS) return HK_ERR_UNSUPPORTED;
   if (fast_supported(prm, dtype)) {
     const bool duo = use_duo(prm);
     prm.flags &= ~kHostSideFlags;  // (the compiled rollout configurations compare flags)
@@ -157,7 +159,11 @@ int params_from_step(const hk_step_desc* s, Params& prm, unsigned internal_stage
   if (s->stages & HK_STAGE_SHIFT) {
     if (!valid_coords_kind(s->coords_kind)) return HK_ERR_UNSUPPORTED;
     if (!s->axis) return HK_ERR_NULL;
-    if (s->axis_dtype < HK_F32 || s->axis_dtype > HK_I64) return HK_ERR_UNSUPPORTED;
+    if (s->axis_dtype == HK_AXIS_MASKED_LOGITS) {
+      if (s->coords_kind != HK_COORDS_CLASS_I32 || s->dtype != HK_F32) return HK_ERR_UNSUPPORTED;
+    } else if (s->axis_dtype < HK_F32 || s->axis_dtype > HK_I64) {
+      return HK_ERR_UNSUPPORTED;
+    }
     if (!aligned(s->axis, (s->axis_dtype == HK_F64 || s->axis_dtype == HK_I64) ? 8 : 4)) return HK_ERR_ALIGN;
     if (s->coords_kind == HK_COORDS_IN_RECORD) {
       if (s->in_stride < n + s->dim) return HK_ERR_SHAPE;

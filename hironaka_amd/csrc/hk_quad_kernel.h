@@ -551,7 +551,8 @@ enum QuadAct : int {
   kActMaskF32AxisI32 = 1,  // [B, d] float32 multi-binary mask (contiguous) + int32 axis: bench.py, get_take_actions
   kActMaskF32AxisI64 = 2,  // ... + int64 axis: torch.argmax of the opponent's one-hot (recurrent_fn.py)
   kActMaskF32AxisF32 = 3,  // ... + float32 axis: the JAX trainer's arrays (jax_trainer.py:528)
-  kActClassI32AxisI32 = 4  // [B] int32 class ids + int32 axis: the gym / list surface
+  kActClassI32AxisI32 = 4,  // [B] int32 class ids + int32 axis: the gym / list surface
+  kActClassI32Logits = 5    // [B] int32 class ids + [B, d] float32 agent logits (HK_AXIS_MASKED_LOGITS): the search's expansion
 };
 
 inline int quad_act_of(const Params& prm) {
@@ -562,6 +563,7 @@ inline int quad_act_of(const Params& prm) {
     if (prm.axis_dtype == HK_F32) return kActMaskF32AxisF32;
   }
   if (prm.coords_kind == HK_COORDS_CLASS_I32 && prm.axis_dtype == HK_I32) return kActClassI32AxisI32;
+  if (prm.coords_kind == HK_COORDS_CLASS_I32 && prm.axis_dtype == HK_AXIS_MASKED_LOGITS) return kActClassI32Logits;
   return kActAny;
 }
 
@@ -582,9 +584,11 @@ __device__ __forceinline__ void quad_actions_issue(QuadActions<D, ACT>& a, const
   if constexpr (ACT == kActAny) {
     fast_fetch_actions<D>(prm, g0 + gi, m, a.raw);
   } else {
-    if constexpr (ACT == kActClassI32AxisI32) a.cword = ((const uint32_t*)prm.coords + g0)[gi];
+    if constexpr (ACT == kActClassI32AxisI32 || ACT == kActClassI32Logits) a.cword = ((const uint32_t*)prm.coords + g0)[gi];
     else a.cword = ((const uint32_t*)prm.coords + g0 * D)[gi * D + (unsigned)(j < D ? j : D - 1)];
-    if constexpr (ACT == kActMaskF32AxisI64) {
+    if constexpr (ACT == kActClassI32Logits) {  // lane k of the quad fetches logit k
+      a.aword = ((const uint32_t*)prm.axis + g0 * D)[gi * D + (unsigned)(j < D ? j : D - 1)];
+    } else if constexpr (ACT == kActMaskF32AxisI64) {
       a.aword = ((const uint32_t*)prm.axis + 2 * g0)[2 * gi];
       a.aword_hi = ((const uint32_t*)prm.axis + 2 * g0)[2 * gi + 1];
     } else {
@@ -608,13 +612,14 @@ __device__ __forceinline__ void quad_actions_decode(const QuadActions<D, ACT>& a
   if constexpr (ACT == kActAny) {
     fast_decode_actions<D>(prm, a.raw, c, axis);
   } else {
-    if constexpr (ACT == kActClassI32AxisI32) {
+    uint32_t subset = 0;
+    if constexpr (ACT == kActClassI32AxisI32 || ACT == kActClassI32Logits) {
       constexpr int ncls = (1 << D) - D - 1;
       int cls = (int)a.cword;
       cls = cls < 0 ? 0 : (cls >= ncls ? ncls - 1 : cls);
-      const uint32_t v = decode_class(cls, D);
+      subset = decode_class(cls, D);
 #pragma unroll
-      for (int k = 0; k < D; ++k) c[k] = (float)((v >> k) & 1u);
+      for (int k = 0; k < D; ++k) c[k] = (float)((subset >> k) & 1u);
     } else {
       // quad_perm [k, k, k, k]: coordinate k sits in lane k of the quad
       c[0] = __int_as_float(qperm_i<0x00>((int)a.cword));
@@ -622,7 +627,25 @@ __device__ __forceinline__ void quad_actions_decode(const QuadActions<D, ACT>& a
       if constexpr (D > 2) c[D > 2 ? 2 : 0] = __int_as_float(qperm_i<0xAA>((int)a.cword));
       if constexpr (D > 3) c[D > 3 ? 3 : 0] = __int_as_float(qperm_i<0xFF>((int)a.cword));
     }
-    if constexpr (ACT == kActMaskF32AxisF32) {
+    if constexpr (ACT == kActClassI32Logits) {
+      // the agent's move: argmax of its logits over the subset's coordinates (jax/util.py:287-327; first maximum, a
+      // NaN beats every number) -- hk_search_masked_argmax in the step's own action decode
+      float lg[D];
+      lg[0] = __int_as_float(qperm_i<0x00>((int)a.aword));
+      if constexpr (D > 1) lg[D > 1 ? 1 : 0] = __int_as_float(qperm_i<0x55>((int)a.aword));
+      if constexpr (D > 2) lg[D > 2 ? 2 : 0] = __int_as_float(qperm_i<0xAA>((int)a.aword));
+      if constexpr (D > 3) lg[D > 3 ? 3 : 0] = __int_as_float(qperm_i<0xFF>((int)a.aword));
+      int best = 0;
+      float bv = (subset & 1u) ? lg[0] : -INFINITY;
+#pragma unroll
+      for (int k = 1; k < D; ++k) {
+        const float v = ((subset >> k) & 1u) ? lg[k] : -INFINITY;
+        const bool better = (v > bv) || (v != v && bv == bv);
+        best = better ? k : best;
+        bv = better ? v : bv;
+      }
+      axis = best;
+    } else if constexpr (ACT == kActMaskF32AxisF32) {
       const float f = __uint_as_float(a.aword);  // `arange(d) == axis`: non-integral / out-of-range match nothing
       const int i = (int)f;
       axis = (f >= 0.0f && f < (float)D && (float)i == f) ? i : -1;
@@ -1070,8 +1093,18 @@ int launch_quad_w(Params prm, hipStream_t stream) {
       case kActMaskF32AxisI64: launch_quad_k<M, D, WPB, kHotJax, kActMaskF32AxisI64>(prm, grid, stream); break;
       case kActMaskF32AxisF32: launch_quad_k<M, D, WPB, kHotJax, kActMaskF32AxisF32>(prm, grid, stream); break;
       case kActClassI32AxisI32: launch_quad_k<M, D, WPB, kHotJax, kActClassI32AxisI32>(prm, grid, stream); break;
+      case kActClassI32Logits:
+        if constexpr (D <= kQuad && !QuadGeom<M, D>::kBig) {
+          launch_quad_k<M, D, WPB, kHotJax, kActClassI32Logits>(prm, grid, stream);
+          break;
+        } else {
+          return HK_ERR_UNSUPPORTED;
+        }
       default: launch_quad_k<M, D, WPB, kHotJax, kActAny>(prm, grid, stream);
     }
+  } else if (act == kActClassI32Logits) {
+    if constexpr (D <= kQuad && !QuadGeom<M, D>::kBig) launch_quad_k<M, D, WPB, kHotNone, kActClassI32Logits>(prm, grid, stream);
+    else return HK_ERR_UNSUPPORTED;
   } else if (act == kActClassI32AxisI32) {
     launch_quad_k<M, D, WPB, kHotNone, kActClassI32AxisI32>(prm, grid, stream);
   } else if (act == kActMaskF32AxisI64) {

@@ -113,7 +113,8 @@ def step(points: torch.Tensor, coords=None, axis=None, *, stages: int, flags: in
         observation, or agent observation whose last d columns are the subset mask --
         ``coords_in_record=True``; jax/util.py:58-74).
     coords: [B, d] multi-binary mask (any numeric dtype) or [B] class ids (int32/int64).
-    axis: [B] int or float.
+    axis: [B] int or float; or [B, d] float32 logits of the agent (with class-id coords): its move is the argmax over
+        the subset's coordinates, decoded inside the kernel (shapes with a four-lane step kernel only).
     want: any of "done", "prev_done", "reward", "num_points".
     Returns {"points": [B, m, d] (or `out`), ...}."""
     pts, orig = _state(points)
@@ -142,12 +143,20 @@ def step(points: torch.Tensor, coords=None, axis=None, *, stages: int, flags: in
     s.coords_kind = A.HK_COORDS_NONE
     if stages & A.HK_STAGE_SHIFT:
         ax = _aux(axis, pts, "axis")
-        if ax is None or ax.shape != (b,):
-            raise ValueError(f"axis must have shape ({b},)")
-        if ax.dtype == torch.uint8:
-            ax = ax.to(torch.int32)
-        keep.append(ax)
-        s.axis, s.axis_dtype = ax.data_ptr(), _TORCH2HK[ax.dtype]
+        if ax is not None and ax.dim() == 2:
+            # [B, d] float32 logits of the agent: its move is the argmax over the subset's coordinates
+            # (HK_AXIS_MASKED_LOGITS; four-lane step kernel only -- HironakaHipError(HK_ERR_UNSUPPORTED) otherwise)
+            if ax.shape != (b, d) or ax.dtype != torch.float32 or not ax.is_contiguous():
+                raise ValueError(f"agent logits must be a contiguous float32 tensor of shape ({b}, {d})")
+            keep.append(ax)
+            s.axis, s.axis_dtype = ax.data_ptr(), A.HK_AXIS_MASKED_LOGITS
+        else:
+            if ax is None or ax.shape != (b,):
+                raise ValueError(f"axis must have shape ({b},)")
+            if ax.dtype == torch.uint8:
+                ax = ax.to(torch.int32)
+            keep.append(ax)
+            s.axis, s.axis_dtype = ax.data_ptr(), _TORCH2HK[ax.dtype]
         if coords_in_record:
             s.coords_kind = A.HK_COORDS_IN_RECORD
         else:

@@ -15,6 +15,8 @@ from typing import Callable, NamedTuple, Tuple
 
 import torch
 
+from . import _abi as A
+from ._lib import HironakaHipError
 from .functional import flatten, get_dones, get_preprocess_fns, get_take_actions, make_agent_obs
 from .host_action_preprocess import get_batch_decode, get_batch_decode_from_one_hot, num_classes
 
@@ -49,6 +51,7 @@ class HostExpander:
         self.scale_observation = scale_observation
         self.reward_sign = reward_sign
         self.stages = ops.make_stages(shift=True, reposition=reposition, newton=True, rescale=rescale_points)
+        self.logits_in_step = None  # unknown until the first expansion
 
     def accepts(self, root_embedding: torch.Tensor) -> bool:
         return (root_embedding.is_cuda and root_embedding.dtype == torch.float32 and root_embedding.dim() == 2
@@ -93,10 +96,23 @@ class HostExpander:
               "hk_search_expand_gather")
         logits, _ = self.agent_model(agent_feat, agent_params)
         logits = logits.to(torch.float32).contiguous()
-        check(L.hk_search_masked_argmax(logits.data_ptr(), action.data_ptr(), axis.data_ptr(), b, d, stream),
-              "hk_search_masked_argmax")
-        res = ops.step(obs, action, axis, stages=self.stages, spec=(m, d), out=points[slot],
-                       want=("done", "prev_done", "reward"), reward_sign=self.reward_sign)
+        want = ("done", "prev_done", "reward")
+        if self.logits_in_step is not False:
+            # the agent's masked argmax inside the step's action decode (HK_AXIS_MASKED_LOGITS: shapes with a four-lane
+            # step kernel); found out once, on the first expansion (eager, before any graph capture)
+            try:
+                res = ops.step(obs, action, logits, stages=self.stages, spec=(m, d), out=points[slot], want=want,
+                               reward_sign=self.reward_sign)
+                self.logits_in_step = True
+            except HironakaHipError as err:
+                if self.logits_in_step or err.status != A.HK_ERR_UNSUPPORTED:
+                    raise
+                self.logits_in_step = False
+        if self.logits_in_step is False:
+            check(L.hk_search_masked_argmax(logits.data_ptr(), action.data_ptr(), axis.data_ptr(), b, d, stream),
+                  "hk_search_masked_argmax")
+            res = ops.step(obs, action, axis, stages=self.stages, spec=(m, d), out=points[slot], want=want,
+                           reward_sign=self.reward_sign)
         host_feat = ops.get_features(points[slot], self.scale_observation, spec=(m, d), out=features[slot])
         prior, value = self.host_model(host_feat, host_params)
         return RecurrentFnOutput(reward=res["reward"], discount=state["discount"], prior_logits=prior,

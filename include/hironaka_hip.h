@@ -80,6 +80,12 @@ extern "C" {
 #define HK_COORDS_CLASS_I64 17
 #define HK_COORDS_IN_RECORD 18 /* mask is the `dim` elements after the points in the input
                                   record (agent observation, jax/util.py:66-74)            */
+/* ---- `axis_dtype` beyond the scalar dtypes ------------------------------------------------ */
+#define HK_AXIS_MASKED_LOGITS 32 /* `axis` is [batch, dim] float32 logits of the agent; its move is the argmax over
+                                    the coordinates of the host's subset (jax/util.py:287-327: action mask + argmax;
+                                    first maximum, NaN beats every number).  Needs HK_COORDS_CLASS_I32 and a shape
+                                    with a four-lane step kernel (float32, contiguous records of (10,3) (20,3) (20,4)):
+                                    anything else returns HK_ERR_UNSUPPORTED                 */
 #define HK_COORDS_NONE 19      /* no shift stage                                           */
 
 /* ---- pipeline stages (bitmask) --------------------------------------------------------- */

@@ -774,3 +774,33 @@ def test_features_torch_matches_oracle(spec, live_fused):
     if f"{tag}/points" in live_fused.files:
         got = host(ops.get_features_torch(torch.as_tensor(live_fused[f"{tag}/points"]).cuda()))
         assert np.array_equal(got, live_fused[f"{tag}/features"])
+
+
+def test_step_with_agent_logits_equals_masked_argmax_then_step():
+    """HK_AXIS_MASKED_LOGITS (the agent's move decoded inside hk_step from its logits and the host's class id) against
+    hk_search_masked_argmax followed by a plain step, on the shapes with a four-lane kernel; elsewhere the status is
+    HK_ERR_UNSUPPORTED"""
+    from hironaka_amd._lib import HironakaHipError, check, lib
+    rng = np.random.default_rng(5)
+    for (m, d) in ((20, 3), (10, 3), (20, 4)):
+        for b in (1, 33, 1000):
+            for stages in (A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON,
+                           A.HK_STAGE_SHIFT | A.HK_STAGE_NEWTON | A.HK_STAGE_RESCALE):
+                P = ops.generate_points(b, m, d, 20, seed=3)
+                cls = torch.tensor(rng.integers(0, 2 ** d - d - 1, b), dtype=torch.int32, device="cuda")
+                lg = rng.standard_normal((b, d)).astype(np.float32)
+                lg[rng.random((b, d)) < 0.1] = np.nan
+                lg[rng.random((b, d)) < 0.15] = 0.25
+                logits = torch.tensor(lg, device="cuda")
+                axis = torch.empty(b, dtype=torch.int32, device="cuda")
+                check(lib().hk_search_masked_argmax(logits.data_ptr(), cls.data_ptr(), axis.data_ptr(), b, d, None), "argmax")
+                want = ("done", "prev_done", "reward", "num_points")
+                ref = ops.step(P, cls, axis, stages=stages, want=want)
+                got = ops.step(P, cls, logits, stages=stages, want=want)
+                for k in ref:
+                    assert torch.equal(ref[k], got[k]), (m, d, b, stages, k)
+    P = ops.generate_points(8, 16, 3, 20, seed=3)  # no four-lane kernel for (16,3)
+    with pytest.raises(HironakaHipError) as err:
+        ops.step(P, torch.zeros(8, dtype=torch.int32, device="cuda"), torch.zeros((8, 3), device="cuda"),
+                 stages=A.HK_STAGE_SHIFT | A.HK_STAGE_NEWTON)
+    assert err.value.status == A.HK_ERR_UNSUPPORTED
