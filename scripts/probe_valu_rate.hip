@@ -50,6 +50,22 @@ __global__ __launch_bounds__(64) void rate_kernel(float* out, int iters, float s
 #define X(k) asm volatile("v_min_u32 %0, %1, %0" : "+v"(r##k) : "v"(a));
         REP8(X)
 #undef X
+      } else if constexpr (CLASS == 9) {  // v_max_f32 (VOP2)
+#define X(k) asm volatile("v_max_f32 %0, %1, %0" : "+v"(r##k) : "v"(a));
+        REP8(X)
+#undef X
+      } else if constexpr (CLASS == 10) {  // v_med3_f32 (what hk_fmin / hk_fmax compile to)
+#define X(k) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(r##k) : "v"(a), "v"(b));
+        REP8(X)
+#undef X
+      } else if constexpr (CLASS == 11) {  // the pair test with vcc forms: 3 sub, max3, min3, min, cmp vcc, cndmask vcc, max
+#define X(k) asm volatile("v_sub_f32 %0, %0, %1\n\tv_sub_f32 %0, %0, %2\n\tv_sub_f32 %0, %0, %1\n\tv_max3_f32 %0, %0, %1, %2\n\tv_min3_f32 %0, %0, %1, %2\n\tv_min_f32 %0, %1, %0\n\tv_cmp_lt_f32_e32 vcc, 0, %0\n\tv_cndmask_b32_e32 %0, %1, %0, vcc\n\tv_max_f32 %0, %2, %0" : "+v"(r##k) : "v"(a), "v"(b) : "vcc");
+        REP8(X)
+#undef X
+      } else if constexpr (CLASS == 12) {  // ... and as the compiler emits it: cmp -> SGPR pair, cndmask e64, med3 accumulators
+#define X(k) asm volatile("v_sub_f32 %0, %0, %1\n\tv_sub_f32 %0, %0, %2\n\tv_sub_f32 %0, %0, %1\n\tv_max3_f32 %0, %0, %1, %2\n\tv_min3_f32 %0, %0, %1, %2\n\tv_med3_f32 %0, %0, %1, %2\n\tv_cmp_lt_f32_e64 s[20:21], 0, %0\n\tv_cndmask_b32_e64 %0, %1, -%0, s[20:21]\n\tv_med3_f32 %0, %0, %2, %1" : "+v"(r##k) : "v"(a), "v"(b) : "s20", "s21");
+        REP8(X)
+#undef X
       } else if constexpr (CLASS == 8) {  // the pair test's shape: 3 sub, max3, min3, cmp->sgpr, cndmask, min (per chain pair)
 #define X(k) asm volatile("v_sub_f32 %0, %0, %1\n\tv_max3_f32 %0, %0, %1, %2\n\tv_cmp_lt_f32_e64 s[20:21], 0, %0\n\tv_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(r##k) : "v"(a), "v"(b) : "s20", "s21");
         REP8(X)
@@ -84,10 +100,11 @@ int main() {
   const int iters = 20000;
   const char* names[] = {"v_add_f32 (VOP2)", "v_max3_f32 (VOP3)", "v_cndmask sgpr mask (VOP3)", "v_mov_b32 dpp quad_perm",
                          "v_sub_f32 dpp", "v_cmp -> sgpr pair (VOP3)", "v_cmp vcc + v_cndmask vcc", "v_min_u32 (VOP2)",
-                         "sub, max3, cmp->sgpr, cndmask"};
-  const int per_iter[] = {64, 64, 64, 64, 64, 64, 128, 64, 256};
+                         "sub, max3, cmp->sgpr, cndmask", "v_max_f32 (VOP2)", "v_med3_f32 (VOP3)",
+                         "pair test, vcc forms (9 instr)", "pair test, as compiled (9 instr)"};
+  const int per_iter[] = {64, 64, 64, 64, 64, 64, 128, 64, 256, 64, 64, 576, 576};
   printf("ns per wave64 instruction per SIMD (2.4 GHz: 2 cycles = 0.83 ns, 4 cycles = 1.67 ns)\n");
-  for (int c = 0; c < 9; ++c) {
+  for (int c = 0; c < 13; ++c) {
     double v[3];
     int w[3] = {1, 2, 4};
     for (int k = 0; k < 3; ++k) {
@@ -100,7 +117,11 @@ int main() {
         case 5: v[k] = run<5>(out, w[k], iters, per_iter[c]); break;
         case 6: v[k] = run<6>(out, w[k], iters, per_iter[c]); break;
         case 7: v[k] = run<7>(out, w[k], iters, per_iter[c]); break;
-        default: v[k] = run<8>(out, w[k], iters, per_iter[c]); break;
+        case 8: v[k] = run<8>(out, w[k], iters, per_iter[c]); break;
+        case 9: v[k] = run<9>(out, w[k], iters, per_iter[c]); break;
+        case 10: v[k] = run<10>(out, w[k], iters, per_iter[c]); break;
+        case 11: v[k] = run<11>(out, w[k], iters / 4, per_iter[c]); break;
+        default: v[k] = run<12>(out, w[k], iters / 4, per_iter[c]); break;
       }
     }
     printf("%-34s  1 wave/SIMD %.2f   2 waves %.2f   4 waves %.2f\n", names[c], v[0], v[1], v[2]);
