@@ -5,7 +5,7 @@ descriptors with host pointers) can import it without a GPU.
 """
 import ctypes as C
 
-HK_ABI_VERSION = 1
+HK_ABI_VERSION = 2
 
 # status codes
 HK_OK = 0

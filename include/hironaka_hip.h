@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define HK_ABI_VERSION 1
+#define HK_ABI_VERSION 2 /* 2: + HK_AXIS_MASKED_LOGITS, hk_rollout_values, hk_search_expand_* / _masked_argmax / _mask_logits */
 
 /* ---- status codes -------------------------------------------------------------------- */
 #define HK_OK 0
