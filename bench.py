@@ -530,8 +530,8 @@ def main():
                    "policy_network": "stand-in: fixed random MLPs 60-256-5 / 63-256-4 behind the HIP feature "
                                      "transform (the reference's flax networks are out of scope)",
                    "launches": "one hipGraph per search (32 simulations), replayed per move; expansions through the "
-                               "fused operators (hk_search_expand_gather, hk_step with the agent's logits as its axis, "
-                               "hk_get_features; node-major tables: no scatter)",
+                               "fused operators (hk_search_expand_gather, hk_step_features: the step with the agent's "
+                               "logits as its axis and the features of its result; node-major tables: no scatter)",
                    "seconds_per_simulate": dt5, "env_steps_in_search_per_s": env5 / dt5,
                    "searches_per_s": cfg["eval_batch_size"] * EPISODE / dt5, "samples": shape5,
                    "seconds_per_simulate_agent_role": dt5_agent,

@@ -153,6 +153,7 @@ PROTOTYPES = {
     "hk_get_features": (C.c_int, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _d, _vp]),
     "hk_get_features_torch": (C.c_int, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _d, _vp]),
     "hk_decode_host_class": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
+    "hk_step_features": (C.c_int, [C.POINTER(hk_step_desc), _vp, _i, _vp]),
     "hk_rollout_values": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_float, C.c_float, _vp]),
     "hk_search_expand_gather": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "hk_search_masked_argmax": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),

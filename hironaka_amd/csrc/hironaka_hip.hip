@@ -247,6 +247,21 @@ int hk_step(const hk_step_desc* desc, void* stream) {
   return launch(prm, desc->dtype, (hipStream_t)stream);
 }
 
+int hk_step_features(const hk_step_desc* desc, void* features_out, int scale_observation, void* stream) {
+  Params prm{};
+  const int st = params_from_step(desc, prm);
+  if (st != HK_OK) return st;
+  if (prm.batch == 0) return HK_OK;
+  if (!features_out) return HK_ERR_NULL;
+  if (!aligned(features_out, 16)) return HK_ERR_ALIGN;
+  if (desc->dtype != HK_F32 || !(prm.stages & HK_STAGE_SHIFT)) return HK_ERR_UNSUPPORTED;
+  prm.feat_out = (float*)features_out;
+  prm.feat_scale = scale_observation ? 1 : 0;
+  if (!use_quad(prm, desc->dtype)) return HK_ERR_UNSUPPORTED;
+  prm.flags &= ~kHostSideFlags;
+  return launch_quad(prm, (hipStream_t)stream);
+}
+
 int hk_shift(const void* points_in, void* points_out, const void* coords, int coords_kind,
              const void* axis, int axis_dtype, int batch, int max_points, int dim, int dtype,
              double padding_value, uint32_t flags, void* stream) {

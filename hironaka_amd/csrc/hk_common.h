@@ -83,6 +83,9 @@ struct Params {
   // grids), so that deferred counts of different launches meet in one workspace
   uint32_t count_stride;
   float pad_f32;  // (float)pad, filled in by launchers whose kernels would otherwise convert per wave
+  // hk_step_features (four-lane kernel): the observation features of the step's RESULT as a second output
+  float* feat_out;     // [batch, m * d] or NULL
+  int32_t feat_scale;  // rescale before the sort (scale_observation)
 };
 
 // hipGetLastError() is sticky per host thread and other users of the runtime in this process

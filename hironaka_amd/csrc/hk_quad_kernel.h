@@ -660,7 +660,10 @@ __device__ __forceinline__ void quad_actions_decode(const QuadActions<D, ACT>& a
 // ---- the kernel: single steps with the caller's actions (hk_step) -----------------------------------------------
 // HOT: kHotJax = the JAX trainer's take_actions (shift + reposition + Newton polytope, JAX semantics) compiled in.
 // register budget: four waves per SIMD (<= 128 VGPRs), three for the large games (<= 168; their LDS allows no more)
-template <int M, int D, int HOT, int WPB, int ACT>
+// FEAT: hk_step_features -- the observation features of the result (jax/util.py:172-214: [rescale] + rows in descending
+// key order, equal keys in row order) as a second output of the same launch: the bucket body has the result's rows in
+// registers, ranks them (qd_ranks_stable) and builds the sorted image in the compact region, which is free by then.
+template <int M, int D, int HOT, int WPB, int ACT, bool FEAT = false>
 __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void quad_kernel(const float* in0, int64_t in_stride0, int batch0,
                                                            const Params prm) {
   using G = QuadGeom<M, D>;
@@ -893,6 +896,35 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void 
       }
 #endif
       np = qd_stages<M, G::CW, R, D, NB>(q, c, axis_in, np, j, flags, stages, cmine, M, list_sorted, rank);
+      if constexpr (FEAT) {
+        static_assert(G::kCompact >= G::kImage, "the features image is built in the compact region");
+        // (every lane has read its slots: the compact region is free)  padding everywhere, then the survivors --
+        // rescaled if asked -- at their rank
+        float fq[R * D];
+        int frank[R];
+#pragma unroll
+        for (int e = 0; e < NB * D; ++e) fq[e] = q[e];
+        if (prm.feat_scale) qd_rescale<R, D, NB>(fq, (unsigned)HK_SEM_JAX);
+        qd_ranks_stable<R, D, NB>(fq, j, false, frank);
+#pragma unroll
+        for (int it = 0; it < G::QL; ++it) {
+          const int qq = lane + it * kWave;
+          if (qq < kQuadGames * G::Q) {
+            if constexpr (G::W == 4) *reinterpret_cast<vf4*>(compact + qq * 4) = vf4{pad, pad, pad, pad};
+            else if constexpr (G::W == 2) *reinterpret_cast<vf2*>(compact + qq * 2) = vf2{pad, pad};
+            else compact[qq] = pad;
+          }
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+          if (fq[s * D] < INFINITY) {
+            float* dst = compact + gi * G::N + frank[s] * D;
+#pragma unroll
+            for (int k = 0; k < D; ++k) dst[k] = fq[s * D + k];
+          }
+        }
+      }
       if (sorted) {
         // list semantics: padding everywhere (the quads fill the wave's image in 16-B pieces), then every survivor at
         // its rank
@@ -1057,6 +1089,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void 
   }
   wave_lds_fence();
   quad_slab_store<M, D>(image, (float*)prm.out + g0 * G::N, ngames, lane);
+  if constexpr (FEAT) quad_slab_store<M, D>(compact, prm.feat_out + g0 * G::N, ngames, lane);
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
@@ -1067,14 +1100,14 @@ constexpr int quad_waves_per_block() {
   return (G::kRegion * 4 * 4 + 4 * kQuadGames * D * 4 <= 64 * 1024) ? 4 : 1;
 }
 
-template <int M, int D, int WPB, int HOT, int ACT>
+template <int M, int D, int WPB, int HOT, int ACT, bool FEAT = false>
 void launch_quad_k(const Params& prm, unsigned grid, hipStream_t stream) {
   size_t dynamic_lds = 0;
 #ifdef HK_QUAD_PROBE  // unused dynamic LDS: caps the workgroups per CU (how much does a second round of waves buy?)
   const char* e = getenv("HK_QUAD_DLDS");
   dynamic_lds = e ? (size_t)atoi(e) : 0;
 #endif
-  hipLaunchKernelGGL((quad_kernel<M, D, HOT, WPB, ACT>), dim3(grid), dim3(kWave * WPB), dynamic_lds, stream,
+  hipLaunchKernelGGL((quad_kernel<M, D, HOT, WPB, ACT, FEAT>), dim3(grid), dim3(kWave * WPB), dynamic_lds, stream,
                      (const float*)prm.in, prm.in_stride, prm.batch, prm);
 }
 
@@ -1087,6 +1120,27 @@ int launch_quad_w(Params prm, hipStream_t stream) {
   launch_prepare();
   const bool hot = prm.flags == HK_SEM_JAX && prm.stages == (HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON);
   const int act = quad_act_of(prm);
+  if (prm.feat_out) {
+    // the step + features launch of the search's expansion: class-id subsets with an int32 axis or the agent's logits,
+    // JAX or torch semantics without a sorted output, small games
+    if constexpr (D <= kQuad && !QuadGeom<M, D>::kBig) {
+      const bool plain = !(prm.stages & kStageFeatureSorts) && (prm.flags & HK_SEM_MASK) != HK_SEM_LIST &&
+                         !(prm.flags & HK_FLAG_COMPACT_SORTED);
+      if (!plain) return HK_ERR_UNSUPPORTED;
+      if (act == kActClassI32Logits) {
+        if (hot) launch_quad_k<M, D, WPB, kHotJax, kActClassI32Logits, true>(prm, grid, stream);
+        else launch_quad_k<M, D, WPB, kHotNone, kActClassI32Logits, true>(prm, grid, stream);
+      } else if (act == kActClassI32AxisI32) {
+        if (hot) launch_quad_k<M, D, WPB, kHotJax, kActClassI32AxisI32, true>(prm, grid, stream);
+        else launch_quad_k<M, D, WPB, kHotNone, kActClassI32AxisI32, true>(prm, grid, stream);
+      } else {
+        return HK_ERR_UNSUPPORTED;
+      }
+      return launch_status();
+    } else {
+      return HK_ERR_UNSUPPORTED;
+    }
+  }
   if (hot) {  // the JAX trainer's take_actions, with the trainers' action layouts compiled in
     switch (act) {
       case kActMaskF32AxisI32: launch_quad_k<M, D, WPB, kHotJax, kActMaskF32AxisI32>(prm, grid, stream); break;

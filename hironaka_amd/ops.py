@@ -106,7 +106,8 @@ def _aux(t: Optional[torch.Tensor], like: torch.Tensor, name: str) -> Optional[t
 def step(points: torch.Tensor, coords=None, axis=None, *, stages: int, flags: int = 0,
          padding_value: float = -1.0, reward_sign: float = 1.0, spec: Optional[Tuple[int, int]] = None,
          coords_in_record: bool = False, out: Optional[torch.Tensor] = None,
-         want: Sequence[str] = ()) -> Dict[str, torch.Tensor]:
+         want: Sequence[str] = (), features_out: Optional[torch.Tensor] = None,
+         scale_observation: bool = True) -> Dict[str, torch.Tensor]:
     """One fused transition (hk_step).
 
     points: [B, m, d] state, or a [B, stride] record matrix with ``spec=(m, d)`` (flattened host
@@ -116,6 +117,9 @@ def step(points: torch.Tensor, coords=None, axis=None, *, stages: int, flags: in
     axis: [B] int or float; or [B, d] float32 logits of the agent (with class-id coords): its move is the argmax over
         the subset's coordinates, decoded inside the kernel (shapes with a four-lane step kernel only).
     want: any of "done", "prev_done", "reward", "num_points".
+    features_out: [B, m*d] contiguous float32 -- the observation features of the RESULT (get_features of the new
+        points, rescaled first if `scale_observation`) written by the same launch (hk_step_features: shapes with a
+        four-lane step kernel, class-id coords; HironakaHipError(HK_ERR_UNSUPPORTED) otherwise).
     Returns {"points": [B, m, d] (or `out`), ...}."""
     pts, orig = _state(points)
     if pts.dim() == 3:
@@ -192,7 +196,15 @@ def step(points: torch.Tensor, coords=None, axis=None, *, stages: int, flags: in
     s.batch, s.max_points, s.dim, s.dtype = b, m, d, _TORCH2HK[pts.dtype]
     s.stages, s.flags = stages, flags | _forced_flags
     with torch.cuda.device(dev):
-        check(lib().hk_step(C.byref(s), _stream(pts)), "hk_step")
+        if features_out is not None:
+            if (not features_out.is_cuda or features_out.dtype != torch.float32 or not features_out.is_contiguous()
+                    or tuple(features_out.shape) != (b, m * d)):
+                raise ValueError(f"features_out must be a contiguous float32 [{b}, {m * d}] tensor on the device")
+            check(lib().hk_step_features(C.byref(s), features_out.data_ptr(), int(bool(scale_observation)),
+                                         _stream(pts)), "hk_step_features")
+            res["features"] = features_out
+        else:
+            check(lib().hk_step(C.byref(s), _stream(pts)), "hk_step")
     if out is None and orig != out_t.dtype:
         out_t = out_t.to(orig)
     res["points"] = out_t

@@ -52,6 +52,7 @@ class HostExpander:
         self.reward_sign = reward_sign
         self.stages = ops.make_stages(shift=True, reposition=reposition, newton=True, rescale=rescale_points)
         self.logits_in_step = None  # unknown until the first expansion
+        self.features_in_step = None
 
     def accepts(self, root_embedding: torch.Tensor) -> bool:
         return (root_embedding.is_cuda and root_embedding.dtype == torch.float32 and root_embedding.dim() == 2
@@ -97,6 +98,21 @@ class HostExpander:
         logits, _ = self.agent_model(agent_feat, agent_params)
         logits = logits.to(torch.float32).contiguous()
         want = ("done", "prev_done", "reward")
+        if self.features_in_step is not False:
+            # everything between the two networks in ONE launch: the agent's masked argmax, the step, the features of
+            # the new node (hk_step_features); found out once, on the first expansion (eager, before any capture)
+            try:
+                res = ops.step(obs, action, logits, stages=self.stages, spec=(m, d), out=points[slot], want=want,
+                               reward_sign=self.reward_sign, features_out=features[slot],
+                               scale_observation=self.scale_observation)
+                self.features_in_step = True
+                prior, value = self.host_model(features[slot], host_params)
+                return RecurrentFnOutput(reward=res["reward"], discount=state["discount"], prior_logits=prior,
+                                         value=value.reshape(b))
+            except HironakaHipError as err:
+                if self.features_in_step or err.status != A.HK_ERR_UNSUPPORTED:
+                    raise
+                self.features_in_step = False
         if self.logits_in_step is not False:
             # the agent's masked argmax inside the step's action decode (HK_AXIS_MASKED_LOGITS: shapes with a four-lane
             # step kernel); found out once, on the first expansion (eager, before any graph capture)

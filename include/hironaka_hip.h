@@ -36,6 +36,8 @@
  *   hk_get_features          jax/util.py:172-214 get_feature_fn (order_and_rescale)
  *   hk_get_features_torch    core/tensor_points.py:72-74 TensorPoints.get_features
  *   hk_decode_host_class     jax/host_action_preprocess.py:8-65, src/_fn.py:241-325
+ *   hk_step_features         hk_step + hk_get_features of its result in one launch (recurrent_fn.py:84-104 + the
+ *                            policy's feature function)
  *   hk_rollout_values        jax/jax_trainer.py:558-592 rollout_postprocess, jax/util.py:261-284
  *   hk_search_select / _backup / _policy
  *                            the calls into mctx at jax/simulation_fn.py:85-117
@@ -55,7 +57,7 @@
 extern "C" {
 #endif
 
-#define HK_ABI_VERSION 2 /* 2: + HK_AXIS_MASKED_LOGITS, hk_rollout_values, hk_search_expand_* / _masked_argmax / _mask_logits */
+#define HK_ABI_VERSION 2 /* 2: + HK_AXIS_MASKED_LOGITS, hk_step_features, hk_rollout_values, hk_search_expand_* / _masked_argmax / _mask_logits */
 
 /* ---- status codes -------------------------------------------------------------------- */
 #define HK_OK 0
@@ -324,6 +326,13 @@ int hk_search_expand_scatter_agent(const void* points, const void* feat, const v
 /* out[b, k] = logits[b, k] if coordinate k belongs to the subset of class_id[b], else -inf (the agent's action
  * mask, jax/util.py:287-305 in its NaN-free form); out may equal logits                                       */
 int hk_search_mask_logits(const void* logits, const int32_t* class_id, void* out, int batch, int dim, void* stream);
+
+/* hk_step with the observation features of its RESULT (hk_get_features of points_out) as a second output of the
+ * same launch: features_out [batch, max_points*dim] contiguous float32.  The search's expansion (recurrent_fn.py:84-104
+ * followed by the policy network's feature function, jax/util.py:172-214).  Four-lane step kernel only: float32,
+ * contiguous records of (10,3) (20,3) (20,4), HK_COORDS_CLASS_I32 with an int32 axis or HK_AXIS_MASKED_LOGITS, JAX or
+ * torch semantics; anything else returns HK_ERR_UNSUPPORTED (call hk_step and hk_get_features instead).          */
+int hk_step_features(const hk_step_desc* desc, void* features_out, int scale_observation, void* stream);
 
 /* ---- value targets of a self-play rollout: JAXTrainer.rollout_postprocess (jax_trainer.py:558-592) with
  * calculate_value_using_reward_fn (jax/util.py:261-284) ----------------------------------------------------------

@@ -37,7 +37,7 @@ def lib() -> C.CDLL:
         protos = {}
         for name, (res, args) in A.PROTOTYPES.items():
             if name in ("hk_abi_version", "hk_strerror", "hk_has_fast_path", "hk_rollout_workspace_bytes",
-                        "hk_rollout_reduce_counts", "hk_rollout_values") or name.startswith("hk_search_"):
+                        "hk_rollout_reduce_counts", "hk_rollout_values", "hk_step_features") or name.startswith("hk_search_"):
                 continue  # launch plumbing / restated in oracle/search_oracle.py and np_oracle.rollout_postprocess
             args = list(args[:-1])  # no stream on the CPU
             protos["hko_" + name[3:]] = (res, args)

@@ -804,3 +804,36 @@ def test_step_with_agent_logits_equals_masked_argmax_then_step():
         ops.step(P, torch.zeros(8, dtype=torch.int32, device="cuda"), torch.zeros((8, 3), device="cuda"),
                  stages=A.HK_STAGE_SHIFT | A.HK_STAGE_NEWTON)
     assert err.value.status == A.HK_ERR_UNSUPPORTED
+
+
+def test_step_features_equals_step_then_get_features():
+    """hk_step_features (the step and the observation features of its result in one launch) against hk_step followed
+    by hk_get_features: class-id subsets with an int32 axis or the agent's logits, with and without rescaling, JAX and
+    torch semantics, hot and run-time configured stage masks; unsupported shapes / layouts say so"""
+    from hironaka_amd._lib import HironakaHipError
+    rng = np.random.default_rng(9)
+    for (m, d) in ((20, 3), (10, 3), (20, 4)):
+        for b in (1, 17, 1000, 4099):
+            for stages, sem in ((7, "jax"), (5, "jax"), (7, "torch"), (15, "jax")):
+                for dense in (False, True):
+                    P = ops.generate_points(b, m, d, 20, seed=b + m, newton=not dense, reposition=not dense)
+                    cls = torch.tensor(rng.integers(0, 2 ** d - d - 1, b), dtype=torch.int32, device="cuda")
+                    ax = torch.tensor(rng.integers(0, d, b), dtype=torch.int32, device="cuda")
+                    logits = torch.tensor(rng.standard_normal((b, d)).astype(np.float32), device="cuda")
+                    fl = ops.make_flags(sem, sem != "jax", sem == "torch")
+                    for axis in (ax, logits):
+                        for scale in (True, False):
+                            ref = ops.step(P, cls, axis, stages=stages, flags=fl, want=("done", "reward"))
+                            want = ops.get_features(ref["points"], scale)
+                            feat = torch.empty((b, m * d), dtype=torch.float32, device="cuda")
+                            got = ops.step(P, cls, axis, stages=stages, flags=fl, want=("done", "reward"),
+                                           features_out=feat, scale_observation=scale)
+                            assert torch.equal(got["points"], ref["points"]) and torch.equal(got["done"], ref["done"])
+                            assert torch.equal(got["reward"], ref["reward"])
+                            assert torch.equal(feat, want), (m, d, b, stages, sem, dense, scale)
+    P = ops.generate_points(8, 20, 3, 20, seed=1)
+    feat = torch.empty((8, 60), dtype=torch.float32, device="cuda")
+    with pytest.raises(HironakaHipError) as err:  # a float mask is not a layout of this operator
+        ops.step(P, torch.ones((8, 3), device="cuda"), torch.zeros(8, dtype=torch.int32, device="cuda"), stages=7,
+                 features_out=feat)
+    assert err.value.status == A.HK_ERR_UNSUPPORTED
