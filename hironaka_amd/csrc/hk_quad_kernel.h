@@ -1121,8 +1121,8 @@ int launch_quad_w(Params prm, hipStream_t stream) {
   const bool hot = prm.flags == HK_SEM_JAX && prm.stages == (HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON);
   const int act = quad_act_of(prm);
   if (prm.feat_out) {
-    // the step + features launch of the search's expansion: class-id subsets with an int32 axis or the agent's logits,
-    // JAX or torch semantics without a sorted output, small games
+    // the step + features launch of the search's expansion: class-id subsets with an int32 axis or the agent's logits
+    // (or, in the JAX trainer's configuration, a float mask with an int32 axis), no sorted output, small games
     if constexpr (D <= kQuad && !QuadGeom<M, D>::kBig) {
       const bool plain = !(prm.stages & kStageFeatureSorts) && (prm.flags & HK_SEM_MASK) != HK_SEM_LIST &&
                          !(prm.flags & HK_FLAG_COMPACT_SORTED);
@@ -1133,6 +1133,8 @@ int launch_quad_w(Params prm, hipStream_t stream) {
       } else if (act == kActClassI32AxisI32) {
         if (hot) launch_quad_k<M, D, WPB, kHotJax, kActClassI32AxisI32, true>(prm, grid, stream);
         else launch_quad_k<M, D, WPB, kHotNone, kActClassI32AxisI32, true>(prm, grid, stream);
+      } else if (act == kActMaskF32AxisI32 && hot) {  // (the agent-role tree: float mask from the embedding)
+        launch_quad_k<M, D, WPB, kHotJax, kActMaskF32AxisI32, true>(prm, grid, stream);
       } else {
         return HK_ERR_UNSUPPORTED;
       }

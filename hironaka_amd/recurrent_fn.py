@@ -153,6 +153,7 @@ class AgentExpander:
         self.scale_observation = scale_observation
         self.reward_sign = reward_sign
         self.stages = ops.make_stages(shift=True, reposition=reposition, newton=True, rescale=rescale_points)
+        self.features_in_step = None  # unknown until the first expansion
 
     def accepts(self, root_embedding: torch.Tensor) -> bool:
         return (root_embedding.is_cuda and root_embedding.dtype == torch.float32 and root_embedding.dim() == 2
@@ -170,6 +171,7 @@ class AgentExpander:
                 "coords": torch.empty((b, d), dtype=torch.float32, device=dev),
                 "agent_feat": torch.empty((b, e + d), dtype=torch.float32, device=dev),
                 "cls": torch.empty(b, dtype=torch.int32, device=dev),
+                "feat": torch.empty((b, e), dtype=torch.float32, device=dev),
                 "discount": torch.full((b,), self.discount, dtype=torch.float32, device=dev)}
 
     def expand(self, params, key, tree, state, parent: torch.Tensor, action: torch.Tensor, node: torch.Tensor):
@@ -187,10 +189,27 @@ class AgentExpander:
         features = state["features"]
         check(L.hk_search_expand_gather_agent(tree.embeddings.data_ptr(), parent.data_ptr(), points.data_ptr(),
                                               coords.data_ptr(), b, n, m, d, stream), "hk_search_expand_gather_agent")
-        res = ops.step(points, coords, action, stages=self.stages, spec=(m, d), want=("done", "prev_done", "reward"),
-                       reward_sign=self.reward_sign)
+        want = ("done", "prev_done", "reward")
+        feat = None
+        if self.features_in_step is not False:
+            # the step and the features of its result in one launch (hk_step_features), where the shape and the stage
+            # mask allow; found out once, on the first expansion (eager, before any capture)
+            try:
+                feat = state["feat"]
+                res = ops.step(points, coords, action, stages=self.stages, spec=(m, d), want=want,
+                               reward_sign=self.reward_sign, features_out=feat,
+                               scale_observation=self.scale_observation)
+                self.features_in_step = True
+            except HironakaHipError as err:
+                if self.features_in_step or err.status != A.HK_ERR_UNSUPPORTED:
+                    raise
+                self.features_in_step = False
+        if self.features_in_step is False:
+            res = ops.step(points, coords, action, stages=self.stages, spec=(m, d), want=want,
+                           reward_sign=self.reward_sign)
         updated = res["points"].reshape(b, e)
-        feat = ops.get_features(updated, self.scale_observation, spec=(m, d))
+        if self.features_in_step is False:
+            feat = ops.get_features(updated, self.scale_observation, spec=(m, d))
         host_logits, _ = self.host_model(feat, host_params)
         host_logits = host_logits.to(torch.float32).contiguous()
         check(L.hk_search_expand_scatter_agent(updated.data_ptr(), feat.data_ptr(), host_logits.data_ptr(),

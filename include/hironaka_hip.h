@@ -330,8 +330,8 @@ int hk_search_mask_logits(const void* logits, const int32_t* class_id, void* out
 /* hk_step with the observation features of its RESULT (hk_get_features of points_out) as a second output of the
  * same launch: features_out [batch, max_points*dim] contiguous float32.  The search's expansion (recurrent_fn.py:84-104
  * followed by the policy network's feature function, jax/util.py:172-214).  Four-lane step kernel only: float32,
- * contiguous records of (10,3) (20,3) (20,4), HK_COORDS_CLASS_I32 with an int32 axis or HK_AXIS_MASKED_LOGITS, JAX or
- * torch semantics; anything else returns HK_ERR_UNSUPPORTED (call hk_step and hk_get_features instead).          */
+ * contiguous records of (10,3) (20,3) (20,4), HK_COORDS_CLASS_I32 with an int32 axis or HK_AXIS_MASKED_LOGITS (JAX or
+ * torch semantics), or a float32 mask with an int32 axis in the JAX trainer's configuration (shift + reposition + Newton); anything else returns HK_ERR_UNSUPPORTED (call hk_step and hk_get_features instead).          */
 int hk_step_features(const hk_step_desc* desc, void* features_out, int scale_observation, void* stream);
 
 /* ---- value targets of a self-play rollout: JAXTrainer.rollout_postprocess (jax_trainer.py:558-592) with

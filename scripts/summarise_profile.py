@@ -24,8 +24,8 @@ os.makedirs(dst, exist_ok=True)
 
 # the launches bench.py's headline numbers come from (kernel name pattern, grid size in threads)
 ROLLOUT = (re.compile(r"duo_kernel<20, 3, 1, 1>"), "131072")   # fused rollout, 65 536 games, two lanes per game
-STEP = (re.compile(r"quad_kernel<20, 3, 1, \d, 1>"), "262144")  # hk_step (JAX-trainer configuration, f32 mask + i32 axis)
-STEP3 = (re.compile(r"quad_kernel<50, 4, 1, \d, 1>"), "1048576")  # hk_step at (50,4) x 262 144
+STEP = (re.compile(r"quad_kernel<20, 3, 1, \d, 1(, false)?>"), "262144")  # hk_step (JAX-trainer configuration, f32 mask + i32 axis)
+STEP3 = (re.compile(r"quad_kernel<50, 4, 1, \d, 1(, false)?>"), "1048576")  # hk_step at (50,4) x 262 144
 
 
 def short(name):

@@ -833,7 +833,12 @@ def test_step_features_equals_step_then_get_features():
                             assert torch.equal(feat, want), (m, d, b, stages, sem, dense, scale)
     P = ops.generate_points(8, 20, 3, 20, seed=1)
     feat = torch.empty((8, 60), dtype=torch.float32, device="cuda")
-    with pytest.raises(HironakaHipError) as err:  # a float mask is not a layout of this operator
-        ops.step(P, torch.ones((8, 3), device="cuda"), torch.zeros(8, dtype=torch.int32, device="cuda"), stages=7,
-                 features_out=feat)
+    # a float mask with an int32 axis: the JAX trainer's stage mask only (the agent-role tree of the search)
+    mask = ops.decode_host_class(torch.tensor(rng.integers(0, 4, 8), dtype=torch.int32, device="cuda"), 3, torch.float32)
+    ax = torch.tensor(rng.integers(0, 3, 8), dtype=torch.int32, device="cuda")
+    ref = ops.step(P, mask, ax, stages=7)
+    got = ops.step(P, mask, ax, stages=7, features_out=feat)
+    assert torch.equal(got["points"], ref["points"]) and torch.equal(feat, ops.get_features(ref["points"], True))
+    with pytest.raises(HironakaHipError) as err:
+        ops.step(P, mask, ax, stages=5, features_out=feat)
     assert err.value.status == A.HK_ERR_UNSUPPORTED
