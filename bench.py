@@ -230,44 +230,67 @@ def main():
         # the same way, jax_trainer.py:513,533-534)
         ops.reduce_counts(count_ws, done_count, b, EPISODE, (m, d))
 
-    g_block = capture(lambda: episodes_deferred(BLOCK)) if n_full >= BLOCK else None
-    g_episode = capture(lambda: episodes_deferred(1))
-    g_rem = capture(lambda: episodes_deferred(1, rem)) if rem else None
-    g_reduce = capture(reduce_counts)
+    def one_region():
+        """exactly K env steps: n_full episodes of 20 steps (+ one shorter episode of K % 20 steps)"""
+        if n_full:
+            episodes_deferred(n_full)
+        if rem:
+            episodes_deferred(1, rem)
+
     launches_per_region = n_full + (1 if rem else 0)
     reduce_every = max(1, BLOCK // max(1, launches_per_region))  # regions between two counter reductions
+    g_episode = capture(lambda: episodes_deferred(1))
+    if distributed:
+        # one rank-local graph per region; the trainer-boundary gather follows EVERY region (SURVEY 8(d) config 4: an
+        # episode, then the all-gather of its final states), timed with its own events
+        group = 1
+        g_region = capture(one_region)
+        g_region_reduce = capture(lambda: (one_region(), reduce_counts()))
+    else:
+        # ONE graph holds `group` regions + the counter reduction, so a short region (the driver's --steps 20 is a
+        # single 12-23 us launch) does not pay a graph replay of its own: the launches of a group run back to back
+        group = reduce_every
+        g_group = capture(lambda: ([one_region() for _ in range(group)], reduce_counts()))
+    gather_events = []
 
-    def region():
-        """exactly K env steps"""
-        for _ in range(n_full // BLOCK):
-            g_block.replay()
-        for _ in range(n_full % BLOCK):
-            g_episode.replay()
-        if g_rem is not None:
-            g_rem.replay()
-
-    def regions(count, start=0):
+    def run_groups(count, start=0, timed=False):
+        """count x group regions (every region = exactly K env steps)"""
+        out = None
         for r in range(start, start + count):
-            region()
-            if (r + 1) % reduce_every == 0:
-                g_reduce.replay()
+            if not distributed:
+                g_group.replay()
+                continue
+            (g_region_reduce if (r + 1) % reduce_every == 0 else g_region).replay()
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = gather_final_states()
+                e1.record()
+                gather_events.append((e0, e1))
+            else:
+                out = gather_final_states()
+        return out
 
     # ---- warm-up (untimed): W steps, then a clock warm-up as long as the measurement ----------------------------
     for _ in range(max(1, W // EPISODE)):
         g_episode.replay()
+    g_reduce = capture(reduce_counts)
     g_reduce.replay()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(SEGMENTS + 1)]
+    run_groups(1)
+    torch.cuda.synchronize()
     ev[0].record()
-    regions(3 * reduce_every)
+    run_groups(3)
     ev[1].record()
     torch.cuda.synchronize()
-    est = max(ev[0].elapsed_time(ev[1]) / 1e3 / (3 * reduce_every), 1e-7)
+    est = max(ev[0].elapsed_time(ev[1]) / 1e3 / 3, 1e-7)  # seconds per group
     per_seg = max(1, math.ceil(MIN_TIMED_S / SEGMENTS / est))
-    per_seg = int(max_over_ranks([math.ceil(per_seg / reduce_every) * reduce_every])[0])  # the same on every rank
-    repeats = SEGMENTS * per_seg
-    regions(repeats)
-    gather_final_states()
+    if distributed:
+        per_seg = math.ceil(per_seg / reduce_every) * reduce_every
+    per_seg = int(max_over_ranks([per_seg])[0])  # the same on every rank
+    repeats = SEGMENTS * per_seg * group  # regions in the timed bracket
+    run_groups(SEGMENTS * per_seg)
     barrier()
 
     # ---- the timed region: `repeats` x exactly K steps ----------------------------------------------------------
@@ -275,10 +298,11 @@ def main():
     barrier()
     t0 = time.perf_counter()
     ev[0].record()
+    final_states = state
     for s in range(SEGMENTS):
-        regions(per_seg, s * per_seg)
+        got = run_groups(per_seg, s * per_seg, timed=True)
+        final_states = got if got is not None else final_states
         ev[s + 1].record()
-    final_states = gather_final_states()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -286,7 +310,11 @@ def main():
     seg_s = max_over_ranks([ev[s].elapsed_time(ev[s + 1]) / 1e3 for s in range(SEGMENTS)])
     assert final_states.shape[0] == world * b
     seg_sorted = sorted(seg_s)
-    median_region_s = 0.5 * (seg_sorted[SEGMENTS // 2 - 1] + seg_sorted[SEGMENTS // 2]) / per_seg
+    median_region_s = 0.5 * (seg_sorted[SEGMENTS // 2 - 1] + seg_sorted[SEGMENTS // 2]) / (per_seg * group)
+    gather_us = None
+    if gather_events:
+        gs = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in gather_events)
+        gather_us = max_over_ranks([gs[len(gs) // 2]])[0]
     timed_episodes = repeats * n_full
     finished = int(done_count[EPISODE].item()) // timed_episodes if timed_episodes else 0
 
@@ -593,14 +621,22 @@ def main():
                             f"host+agent policies sampled in-kernel, reposition=True, rescale=False, episodes of "
                             f"{EPISODE} steps from generate_pts states (max_value={MAX_VALUE}); fused rollout: "
                             f"{EPISODE} env steps per launch",
-                "parallelism": f"{world} x independent game shards, one all-gather of final states inside the "
-                               f"timed region",
-                "launch": f"hipGraph replays: one rollout kernel per episode, one counter reduce per {BLOCK} "
-                          f"episodes; the K-step region repeated {repeats}x inside one barrier+synchronize bracket",
+                "parallelism": f"{world} x independent game shards" + (
+                    f"; after EVERY {K}-step region one all-gather of the final states of all ranks "
+                    f"({os.environ.get('HK_BENCH_GATHER', 'rccl')}), inside the timed region" if distributed else ""),
+                "launch": f"hipGraph replays: one rollout kernel per episode, one counter reduce per "
+                          f"{reduce_every * launches_per_region} episodes, {group} region(s) per graph; the K-step "
+                          f"region repeated {repeats}x inside one barrier+synchronize bracket",
             },
             "roofline": roofline,
             "games_finished_per_episode": finished,
         }
+        if gather_us is not None:
+            out["gather_us"] = gather_us
+            out["gather_bytes_per_rank"] = int(world * b * m * d * 4)
+            out["gather_note"] = ("median over the timed regions of the HIP-event time around the trainer-boundary "
+                                  "all-gather (every rank receives all ranks' final states), max over ranks; it is "
+                                  "inside `value`")
         for key, val in (("single_step", single), ("boundary_step", api), ("single_step_dense", dense),
                          ("overlapped_episodes", overlapped), ("large_batch", large),
                          ("legal_axis_torch_list_semantics", legal),

@@ -43,6 +43,7 @@ HK_FLAG_DEFER_COUNTS = 128
 HK_FLAG_FORCE_ONE_LANE = 256
 HK_FLAG_FORCE_TWO_LANES = 512
 HK_FLAG_FORCE_FOUR_LANES = 1024
+HK_FLAG_FORCE_POOL = 2048
 
 # fused policies
 HK_HOST_RANDOM, HK_HOST_ALL_COORD, HK_HOST_ZEILLINGER = 0, 1, 2

@@ -3,7 +3,9 @@
 // status code.  gfx950 only.
 #include "hk_fast_kernel.h"
 #include "hk_duo_kernel.h"
+#include "hk_pool_kernel.h"
 #include "hk_quad_kernel.h"
+#include "hk_quadroll_kernel.h"
 #include "hk_team_kernel.h"
 #include "hk_search.h"
 #include "hk_generic_kernel.h"
@@ -64,7 +66,7 @@ int launch_generic(Params& prm, int dtype, hipStream_t stream) {
 // specialised shapes on HK_FLAG_FORCE_TEAM) -> generic kernel (anything else: f64, dim > 6, > 64 rows,
 // HK_FLAG_FORCE_GENERIC, and the few mode / semantics combinations fast_supported / team_supported decline)
 constexpr unsigned kHostSideFlags =
-    HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES | HK_FLAG_FORCE_FOUR_LANES;  // kernel selection only
+    HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES | HK_FLAG_FORCE_FOUR_LANES | HK_FLAG_FORCE_POOL;  // kernel selection only
 
 // hk_step on four lanes per game (hk_quad_kernel.h): where it is ahead of the two-lane kernel
 static bool use_quad(const Params& prm, int dtype) {
@@ -76,7 +78,22 @@ static bool use_quad(const Params& prm, int dtype) {
   if (!quad_supported(prm, dtype)) return false;
   return quad_default(prm, device_simds());
 }
+// plain rollouts on four lanes per game (hk_quadroll_kernel.h): forced, or where it is the default
+static bool use_quadroll(const Params& prm, int dtype) {
+  Params probe = prm;
+  probe.flags &= ~(unsigned)HK_FLAG_FORCE_FOUR_LANES;
+  if (!quadroll_supported(probe, dtype)) return false;
+  if (prm.flags & HK_FLAG_FORCE_FOUR_LANES) return true;
+  return quadroll_default(prm, device_simds());
+}
 static bool use_duo(const Params& prm) { return !(prm.flags & HK_FLAG_FORCE_ONE_LANE) && duo_wanted(prm); }
+// plain rollouts on the pool kernel (hk_pool_kernel.h): forced, or where it is ahead of the fixed deals
+static bool use_pool(const Params& prm) {
+  if (!pool_supported(prm)) return false;
+  if (prm.flags & HK_FLAG_FORCE_POOL) return true;
+  if (prm.flags & (HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES)) return false;
+  return pool_default(prm, device_simds());
+}
 
 int launch(Params& prm, int dtype, hipStream_t stream) {
   if (prm.batch == 0) return HK_OK;
@@ -84,12 +101,17 @@ int launch(Params& prm, int dtype, hipStream_t stream) {
     prm.flags &= ~kHostSideFlags;
     return launch_quad(prm, stream);
   }
+  if (use_quadroll(prm, dtype)) {
+    prm.flags &= ~kHostSideFlags;  // (the compiled rollout configurations compare flags)
+    return launch_quadroll(prm, stream);
+  }
   // (the agent's move as an argmax of its logits is decoded by the four-lane kernel only)
   if ((prm.stages & HK_STAGE_SHIFT) && prm.axis_dtype == HK_AXIS_MASKED_LOGITS) return HK_ERR_UNSUPPORTED;
   if (fast_supported(prm, dtype)) {
+    const bool pool = use_pool(prm);
     const bool duo = use_duo(prm);
     prm.flags &= ~kHostSideFlags;  // (the compiled rollout configurations compare flags)
-    return duo ? launch_duo(prm, stream) : launch_fast(prm, stream);
+    return pool ? launch_pool(prm, stream) : duo ? launch_duo(prm, stream) : launch_fast(prm, stream);
   }
   prm.flags &= ~kHostSideFlags;
   if (team_supported(prm, dtype)) {
@@ -102,8 +124,9 @@ int launch(Params& prm, int dtype, hipStream_t stream) {
 // number of workgroups `launch` will use for this request (0: not launchable)
 int64_t planned_grid(Params prm, int dtype) {
   if (prm.batch == 0) return 0;
+  if (use_quadroll(prm, dtype)) return quadroll_grid(prm);
   if (fast_supported(prm, dtype)) {
-    const int gpb = use_duo(prm) ? kDuoGames : fast_games_per_block(prm);
+    const int gpb = use_pool(prm) ? kPoolGames : use_duo(prm) ? kDuoGames : fast_games_per_block(prm);
     return ((int64_t)prm.batch + gpb - 1) / gpb;
   }
   if (team_supported(prm, dtype) && plan_team(prm) == HK_OK)

@@ -393,6 +393,31 @@ __device__ inline void duo_policy_words(uint64_t gg, uint32_t step, uint64_t see
   agent_word = own ? b : ob;
 }
 
+// ---- the policy stream off the critical path (plain rollouts) ------------------------------------------------------
+// A Philox block is ~115 instructions, 20 of them quarter-rate 32 x 32 -> 64 multiplies in a dependent chain of ten
+// rounds: computed inside the step loop (one block per lane every four steps) it was a fifth of the loop's
+// instructions and most of a late step's latency (a step on one slot per lane is ~40 instructions without it).  The
+// words depend on (game, step) only, not on the state: a WINDOW of kDuoPreBlocks blocks per game (24 steps) is
+// computed before the first step -- while the wave would otherwise only wait for its slab -- two independent chains at
+// a time, and parked in LDS as [block][game] x 16 B; a step reads its two words with one ds_read_b64 (both lanes of a
+// pair the same address).  Episodes longer than a window refill it between two passes over the staircase.
+constexpr int kDuoPreBlocks = 12;
+
+// blocks [wb0, wb0 + nb) of the wave's games: lane (gi, h) computes blocks wb0 + h, wb0 + h + 2, ...
+__device__ __forceinline__ void duo_policy_fill(uint32_t* pol, uint64_t gg, uint32_t wb0, int nb, uint64_t seed, int gi,
+                                                int h) {
+#pragma nounroll
+  for (int i = 0; i < kDuoPreBlocks; i += 4) {
+    if (i >= nb) break;  // wave-uniform
+    const uint32_t b0 = (uint32_t)(i + h), b1 = b0 + 2u;
+    const U4 r0 = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), wb0 + b0, kStreamPolicy, seed);
+    const U4 r1 = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), wb0 + b1, kStreamPolicy, seed);
+    typedef uint32_t vu4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<vu4*>(pol + ((int)b0 * kDuoGames + gi) * 4) = vu4{r0.x, r0.y, r0.z, r0.w};
+    *reinterpret_cast<vu4*>(pol + ((int)b1 * kDuoGames + gi) * 4) = vu4{r1.x, r1.y, r1.z, r1.w};
+  }
+}
+
 // ---- the kernel: fused rollouts (MODE kModeRollout; kModeRolloutRec: with per-step observations / records) and
 // single steps with the caller's actions (kModeStep: hk_step) -------------------------------------------------
 template <int M, int D, int MODE, int HOT = kHotNone>
@@ -405,6 +430,8 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   static_assert(M <= 32, "the live mask of a game travels as 32 bits");
   __shared__ __align__(16) float lds[kDuoGames * G::S];
   __shared__ float cbuf[kDuoGames * D];  // slow path only
+  // plain rollouts: the policy words of a window of steps (duo_policy_fill)
+  __shared__ __align__(16) uint32_t pol[(MODE == kModeRollout) ? kDuoPreBlocks * kDuoGames * 4 : 4];
   const int lane = threadIdx.x;
   const int h = lane & 1, gi = lane >> 1;
   const int64_t g0 = (int64_t)blockIdx.x * kDuoGames;
@@ -414,6 +441,8 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   const bool leader = active && h == 0;
   const int64_t g = g0 + gi;
 #ifdef HK_DUO_PROBE  // dev builds (scripts/build_probe.sh): a time line per wave, written over game_length_out
+  __shared__ int32_t probe_buf[24];
+  if (lane < 24) probe_buf[lane] = 0;
   const long long probe_t0 = wall_clock64();
   long long probe_t1 = 0, probe_t2 = 0;
   int probe_steps = 0, probe_smax = 0;
@@ -421,6 +450,13 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   DuoSlabRegs<M, D> slab;
   duo_slab_issue<M, D>(slab, in0, in_stride0, g0, ngames, lane);
   const uint64_t gg = prm.game_offset + (uint64_t)g;
+  // plain rollouts: the first window of policy words, computed while the slab is in flight
+  uint32_t pol_b0 = prm.step_offset >> 1;  // first block of the window (wave-uniform)
+  const uint32_t pol_last = (prm.steps > 0) ? (prm.step_offset + (uint32_t)prm.steps - 1u) >> 1 : pol_b0;
+  if constexpr (MODE == kModeRollout) {
+    const uint32_t nb = pol_last - pol_b0 + 1u;
+    duo_policy_fill(pol, gg, pol_b0, (int)(nb < (uint32_t)kDuoPreBlocks ? nb : (uint32_t)kDuoPreBlocks), prm.seed, gi, h);
+  }
   float* mine = lds + gi * G::S;
   const float pad = (float)prm.pad;
   const unsigned flags = (HOT == kHotJax) ? (unsigned)HK_SEM_JAX : (HOT == kHotTorch) ? kHotTorchFlags : prm.flags;
@@ -550,12 +586,26 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
     static_assert(CH <= 6 || CH % 2 == 0, "bucket ladder: 1..6, then even numbers");
     int t = 0;
     bool stop = false;
+    while (t < nsteps && !stop) {  // one pass per window of policy words (episodes of up to 24 steps: one pass)
+    if ((uint32_t)((step0 + (uint32_t)t) >> 1) - pol_b0 >= (uint32_t)kDuoPreBlocks) {
+      __syncthreads();
+      pol_b0 = (step0 + (uint32_t)t) >> 1;
+      const uint32_t nb = pol_last - pol_b0 + 1u;
+      duo_policy_fill(pol, gg, pol_b0, (int)(nb < (uint32_t)kDuoPreBlocks ? nb : (uint32_t)kDuoPreBlocks), seed, gi, h);
+      __syncthreads();
+    }
+    // last step (exclusive) the window covers
+    const uint32_t wend_abs = (pol_b0 + (uint32_t)kDuoPreBlocks) << 1;
+    const int tw = (wend_abs - step0 < (uint32_t)nsteps) ? (int)(wend_abs - step0) : nsteps;
     DuoLevels<CH>::run([&](auto nbc, auto loc) {
       constexpr int NB = decltype(nbc)::value, LO = decltype(loc)::value;
-      while (t < nsteps && (smax > LO || LO == 0) && !stop) {  // (a wave of empty games has smax 0: the last loop's)
+      while (t < tw && (smax > LO || LO == 0) && !stop) {  // (a wave of empty games has smax 0: the last loop's)
         int axis, cls;
-        uint32_t mask, ra, rb;
-        duo_policy_words(gg, step0 + (uint32_t)t, seed, dcache, h, ra, rb);
+        uint32_t mask;
+        const uint32_t step = step0 + (uint32_t)t;
+        typedef uint32_t vu2 __attribute__((ext_vector_type(2)));
+        const vu2 pw = *reinterpret_cast<const vu2*>(pol + ((int)((step >> 1) - pol_b0) * kDuoGames + gi) * 4 + (step & 1u) * 2u);
+        const uint32_t ra = pw.x, rb = pw.y;
         policy_from_words<D>(ra, rb, host_policy, agent_policy, cls, axis, mask, 0);
         const unsigned st = (end_sort && t + 1 == nsteps) ? (stages & ~(unsigned)HK_STAGE_RESCALE) : stages;
         rescale_pending = end_sort && t + 1 == nsteps && (stages & HK_STAGE_RESCALE);
@@ -595,9 +645,13 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
             duo_gather<M, CH, D, NB>(q, mine, gmask, sprev, h);  // slots [smax, sprev) become holes again
           }
         }
+#ifdef HK_DUO_PROBE  // per-step stamps: the clock and the slots per lane after the step
+        if (lane == 0 && t < 24) probe_buf[t] = (int32_t)((((uint32_t)wall_clock64()) << 4) | (uint32_t)(smax & 15));
+#endif
         ++t;
       }
     });
+    }
 #ifdef HK_DUO_PROBE
     probe_steps = t;
     probe_t2 = wall_clock64();
@@ -699,6 +753,8 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
     w[5] = probe_smax;
     w[6] = (int32_t)blockIdx.x;
     w[7] = (int32_t)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+    if (ngames >= 32)
+      for (int i = 0; i < 24; ++i) w[8 + i] = probe_buf[i];
   }
 #endif
 }

@@ -1,0 +1,563 @@
+// Four lanes per game, fused rollouts: hk_rollout on the four-lane scheme of hk_quad_kernel.h.
+//
+// hk::team_kernel served the rollouts of the large games ((50,4): 800 B per game) with four lanes per game too, but
+// mirrored every row through LDS for the pair test (one broadcast ds_read per row and slot, 38 % of its LDS cycles bank
+// conflicts) inside ONE loop over the steps with a dispatch over the buckets in it: 378 us per 20-step episode of
+// 262 144 games against the ~90 us it takes to move the state once each way.  This kernel is the rollout loop of
+// hk_duo_kernel.h on the quad's data flow:
+//   * 16 games per wave; slab in by LDS-DMA, each lane scans its quarter of the rows, every live row goes to the slot
+//     of its rank in a compact image laid OVER the slab image (rows of 16 B; the row's index in the game travels in a
+//     byte array next to it), lane j reads ranks j, j + 4, ...: rows (and their indices) live in registers from then on;
+//   * the domination test by DPP quad exchanges (qd_newton: own slots' triangle + the lane one up + half of the lane
+//     two up, 2 S^2 tests per lane for S slots), beyond 8 slots per lane the segmented loop over the parked rows
+//     (qd_newton_lds); column minima / maxima through two DPP exchanges; the shift as selects (0/1 subsets);
+//   * a STAIRCASE of step loops, one per bucket of slots per lane, entered from the top down; when the widest game of the
+//     wave fits fewer slots the quads re-deal their rows through the compact image (rank = popcounts of the four lanes'
+//     live masks, no serial scan);
+//   * the policy stream off the critical path: the wave computes the DECODED actions (subset mask, axis) of a window of
+//     24 steps per game before the first step -- while its slab is in flight -- and parks them in LDS, one byte per
+//     game and step; a step reads its byte (all four lanes of a quad the same address).  Philox is keyed by the
+//     global game index and the step as everywhere else: bit-identical results;
+//   * a game's first finished step is kept per game; the per-step finished-game counts are ballots over those at the
+//     end of the launch (a finished game stays finished), not an atomic per step inside the loop;
+//   * fixed-point exit as in the other rollout kernels (every game of the wave without a point, or with one point at the
+//     origin);
+//   * at the end the image is rebuilt (padding everywhere, survivors at their own rows) and stored as one slab.
+// Plain rollouts only (no per-step records, no Zeillinger host -- its choice depends on the state --, no sorted output);
+// exactness guard and whole-wave fallback on the generic routines as in the other kernels.
+#pragma once
+
+#include "hk_quad_kernel.h"
+
+namespace hk {
+
+constexpr int kQrBlocks = 12;              // Philox blocks per game in a window of actions (24 steps)
+constexpr int kQrSteps = 2 * kQrBlocks;
+
+template <int M, int D>
+struct QuadRollGeom {
+  using Q = QuadGeom<M, D>;
+  static constexpr int R = Q::R;
+  static constexpr int CW = (D <= 4) ? 4 : D;                  // floats per compact row
+  static constexpr int kCompact = kQuadGames * M * CW;
+  static constexpr int kRegion = Q::kImage > kCompact ? Q::kImage : kCompact;  // floats: image and compact image alias
+  static constexpr int kTags = (kQuadGames * M + 15) / 16 * 16;                 // bytes
+  static constexpr int kActs = kQrSteps * kQuadGames;                          // bytes (>= the slow path's scratch)
+  static constexpr int kWaveBytes = kRegion * 4 + kTags + kActs;
+  static constexpr bool kBig = kWaveBytes > 12 * 1024;
+  // waves per workgroup: four; one for the large games, whose 160 KB of LDS per CU then hold 11 waves (three waves
+  // per SIMD: <= 168 VGPRs) instead of 8
+  static constexpr int kWpb = kBig ? 1 : 4;
+  static constexpr int kWavesPerSimd = kBig ? 3 : 4;
+  static_assert(D <= 5, "an action travels as a byte: subset mask (D bits) | axis << 5");
+  static_assert(kActs >= kQuadGames * D * 4, "the slow path's subset scratch lies over the action window");
+  // the bucket below nb on the ladder 1..6, 8, 10, 13, 16, ... (QuadGeom::next_bucket), the top bucket being R
+  static constexpr int prev_bucket(int nb) {
+    int p = 0, b = 1;
+    while (b < nb) {
+      p = b;
+      b = Q::next_bucket(b);
+    }
+    return p;
+  }
+};
+
+// f(NB, LO) for every bucket NB from R down, LO the next smaller one (0 below the first)
+template <int M, int D, int NB>
+struct QuadLevels {
+  static constexpr int kLo = QuadRollGeom<M, D>::prev_bucket(NB);
+  template <typename F>
+  static __device__ __forceinline__ void run(F&& f) {
+    f(std::integral_constant<int, NB>{}, std::integral_constant<int, kLo>{});
+    if constexpr (kLo >= 1) QuadLevels<M, D, kLo>::run(f);
+  }
+};
+
+// reposition when every coordinate is >= +0 or the +inf of a hole (in-kernel 0/1 subsets; see d_reposition): unsigned
+// minima of the bit patterns, the quad's through two DPP exchanges
+template <int R, int D, int NB>
+__device__ __forceinline__ void qr_reposition_bin(float (&q)[R * D]) {
+  uint32_t mb[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) mb[k] = __float_as_uint(q[k]);
+#pragma unroll
+  for (int r = 1; r < NB; ++r)
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const uint32_t w = __float_as_uint(q[r * D + k]);
+      mb[k] = w < mb[k] ? w : mb[k];
+    }
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    uint32_t o = (uint32_t)qperm_i<kQuadSwap1>((int)mb[k]);
+    mb[k] = o < mb[k] ? o : mb[k];
+    o = (uint32_t)qperm_i<kQuadUp2>((int)mb[k]);
+    mb[k] = o < mb[k] ? o : mb[k];
+    const float sub = (mb[k] == 0x7F800000u) ? 0.0f : __uint_as_float(mb[k]);
+#pragma unroll
+    for (int r = 0; r < NB; ++r) q[r * D + k] = q[r * D + k] - sub;
+  }
+}
+
+// one transition on slots [0, NB) of the four lanes with the policy's 0/1 subset `cmask`; returns the GAME's live rows
+template <int M, int CW, int R, int D, int NB>
+__device__ __forceinline__ int qr_stages(float (&q)[R * D], uint32_t cmask, int axis, int np, int j, unsigned flags,
+                                         unsigned stages, float* cmine, int smax) {
+  if (stages & HK_STAGE_SHIFT) b_shift_mask<R, D, NB>(q, cmask, axis, np, flags);
+  if (stages & HK_STAGE_REPOSITION) qr_reposition_bin<R, D, NB>(q);
+  if (stages & HK_STAGE_NEWTON) {
+    if constexpr (NB > kQuadDppSlots) {
+      const int slots_end = kQuad * smax < M ? kQuad * smax : M;
+      qd_newton_lds<M, CW, R, D, NB>(q, cmine, j, slots_end);
+    } else {
+      qd_newton<R, D, NB>(q, j);
+    }
+  }
+  if (stages & HK_STAGE_RESCALE) qd_rescale<R, D, NB>(q, flags);
+  int n = 0;
+#pragma unroll
+  for (int r = 0; r < NB; ++r) n += (q[r * D] < INFINITY) ? 1 : 0;
+  return q_sum(n);
+}
+
+// the decoded actions of blocks [wb0, wb0 + nb) of the wave's 16 games: lane l serves game l & 15, blocks (l >> 4) + 4 i.
+// One byte per game and step: subset mask | axis << 5.
+template <int D>
+__device__ __forceinline__ void qr_policy_fill(uint8_t* act, uint64_t gg0, uint32_t wb0, int nb, uint64_t seed,
+                                               int host_policy, int agent_policy, int lane) {
+  const int game = lane & (kQuadGames - 1), sub = lane >> 4;
+  const uint64_t gg = gg0 + (uint64_t)game;
+#pragma nounroll
+  for (int i = 0; i < kQrBlocks; i += 4) {
+    if (i >= nb) break;  // wave-uniform
+    const int b = i + sub;
+    const U4 r = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), wb0 + (uint32_t)b, kStreamPolicy, seed);
+    int cls, axis;
+    uint32_t mask;
+    policy_from_words<D>(r.x, r.y, host_policy, agent_policy, cls, axis, mask, 0);
+    act[(2 * b) * kQuadGames + game] = (uint8_t)(mask | ((uint32_t)axis << 5));
+    policy_from_words<D>(r.z, r.w, host_policy, agent_policy, cls, axis, mask, 0);
+    act[(2 * b + 1) * kQuadGames + game] = (uint8_t)(mask | ((uint32_t)axis << 5));
+  }
+}
+
+// the quad's rows to their ranks in the compact image (rank order = (slot, lane) order = the order they had), the rows'
+// indices next to them; then slots [0, snew) back: lane j takes ranks j, j + 4, ...
+template <int M, int CW, int R, int D, int NB>
+__device__ __forceinline__ void qr_redeal(float (&q)[R * D], int (&orig)[R], float* cmine, uint8_t* tmine, int j, int np,
+                                          int snew) {
+  uint32_t lm = 0;
+#pragma unroll
+  for (int s = 0; s < NB; ++s) lm |= (q[s * D] < INFINITY) ? (1u << s) : 0u;
+  const uint32_t l1 = (uint32_t)qperm_i<kQuadUp1>((int)lm), l2 = (uint32_t)qperm_i<kQuadUp2>((int)lm),
+                 l3 = (uint32_t)qperm_i<kQuadUp3>((int)lm);
+  // the lane k up is lane (j + k) & 3 of the quad: its slot s comes before mine iff that lane index is below j
+  const bool b1 = ((j + 1) & 3) < j, b2 = ((j + 2) & 3) < j, b3 = ((j + 3) & 3) < j;
+#pragma unroll
+  for (int s = 0; s < NB; ++s) {
+    const uint32_t below = (1u << s) - 1u, at = 1u << s;
+    const int rank = __popc(lm & below) + __popc(l1 & (below | (b1 ? at : 0u))) + __popc(l2 & (below | (b2 ? at : 0u))) +
+                     __popc(l3 & (below | (b3 ? at : 0u)));
+    if ((lm >> s) & 1u) {
+      float* dst = cmine + rank * CW;
+      if constexpr (D == 4) {
+        *reinterpret_cast<vf4*>(dst) = vf4{q[s * D], q[s * D + 1], q[s * D + 2], q[s * D + 3]};
+      } else if constexpr (D == 3) {
+        *reinterpret_cast<vf4*>(dst) = vf4{q[s * D], q[s * D + 1], q[s * D + 2], 0.0f};
+      } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) dst[k] = q[s * D + k];
+      }
+      tmine[rank] = (uint8_t)orig[s];
+    }
+  }
+  wave_lds_fence();
+  unrolled_while<0, NB>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (s >= snew) {  // slots past the new bucket are holes again (no live row can sit there: np <= 4 snew)
+#pragma unroll
+      for (int k = 0; k < D; ++k) q[s * D + k] = INFINITY;
+      return true;
+    }
+    const bool has = kQuad * s + j < np;
+    const int r = kQuad * s + j < M ? kQuad * s + j : 0;
+    const float* src = cmine + r * CW;
+    if constexpr (D == 4 || D == 3) {
+      const vf4 v = *reinterpret_cast<const vf4*>(src);
+      q[s * D] = has ? v.x : INFINITY;
+      q[s * D + 1] = has ? v.y : INFINITY;
+      q[s * D + 2] = has ? v.z : INFINITY;
+      if constexpr (D == 4) q[s * D + 3] = has ? v.w : INFINITY;
+    } else {
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const float v = src[k];
+        q[s * D + k] = has ? v : INFINITY;
+      }
+    }
+    orig[s] = (int)tmine[r];
+    return true;
+  });
+  wave_lds_fence();  // (the compact image is scratch again: qd_newton_lds parks rows there)
+}
+
+template <int M, int D, int HOT, int WPB>
+__global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) void quadroll_kernel(
+    const float* in0, int64_t in_stride0, int batch0, const Params prm) {
+  using G = QuadGeom<M, D>;
+  using RG = QuadRollGeom<M, D>;
+  constexpr int R = RG::R, CW = RG::CW;
+  using MaskM = MaskT<M>;
+  static_assert(M <= 255, "a row's index travels as a byte");
+  __shared__ __align__(16) float lds_all[WPB * RG::kRegion];
+  __shared__ __align__(16) uint8_t tag_all[WPB * RG::kTags];
+  __shared__ __align__(16) uint8_t act_all[WPB * RG::kActs];  // (the slow path's subset scratch lies over it)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & (kWave - 1);
+  float* region = lds_all + wave * RG::kRegion;
+  uint8_t* tags = tag_all + wave * RG::kTags;
+  uint8_t* act = act_all + wave * RG::kActs;
+  const int j = lane & 3, gi = lane >> 2;
+  const int64_t g0 = ((int64_t)blockIdx.x * WPB + wave) * kQuadGames;
+  const int64_t left = (int64_t)batch0 - g0;
+  if (left <= 0) return;  // (waves of a workgroup never meet at a barrier)
+  const int ngames = (int)(left < kQuadGames ? left : kQuadGames);
+  const bool active = gi < ngames;
+  const bool leader = active && j == 0;
+  const int64_t g = g0 + gi;
+  quad_slab_load<M, D>(in0 + g0 * G::N, region, ngames, lane);
+  const float pad = prm.pad_f32;
+  const unsigned flags = (HOT == kHotJax) ? (unsigned)HK_SEM_JAX : (HOT == kHotTorch) ? kHotTorchFlags : prm.flags;
+  const unsigned stages = HOT ? (unsigned)(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON) : prm.stages;
+  const float fill = ((flags & HK_SEM_MASK) == HK_SEM_JAX) ? -1.0f : pad;
+  const int nsteps = prm.steps;
+  uint32_t step0 = prm.step_offset;
+  uint64_t seed = prm.seed;
+  int host_policy = prm.host_policy, agent_policy = prm.agent_policy;
+  asm volatile("" : "+s"(step0), "+s"(seed), "+s"(host_policy), "+s"(agent_policy));
+  // the first window of decoded actions, computed while the slab is in flight
+  const uint64_t gg0 = prm.game_offset + (uint64_t)g0;
+  uint32_t wb0 = step0 >> 1;  // first Philox block of the window (wave-uniform)
+  const uint32_t wb_last = nsteps > 0 ? (step0 + (uint32_t)nsteps - 1u) >> 1 : wb0;
+  {
+    const uint32_t nb = wb_last - wb0 + 1u;
+    qr_policy_fill<D>(act, gg0, wb0, (int)(nb < (uint32_t)kQrBlocks ? nb : (uint32_t)kQrBlocks), seed, host_policy,
+                      agent_policy, lane);
+  }
+  float* mine = region + gi * G::N;
+  wait_vmem_all();
+  wave_lds_fence();
+
+  // ---- live rows + exactness guard: lane j looks at rows j*R .. j*R + R - 1 (hk_quad_kernel.h) ------------------------
+  float rows[R * D];
+  const int i0 = j * R;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if constexpr (D == 4) {
+      const vf4 v = *reinterpret_cast<const vf4*>(mine + (i0 + r < M ? i0 + r : M - 1) * D);
+      rows[r * D] = (i0 + r < M) ? v.x : fill;
+      rows[r * D + 1] = (i0 + r < M) ? v.y : fill;
+      rows[r * D + 2] = (i0 + r < M) ? v.z : fill;
+      rows[r * D + 3] = (i0 + r < M) ? v.w : fill;
+    } else {
+#pragma unroll
+      for (int k = 0; k < D; ++k) rows[r * D + k] = (i0 + r < M) ? mine[(i0 + r) * D + k] : fill;
+    }
+  }
+  const uint32_t fill_bits = __float_as_uint(fill);
+  uint32_t lmask = 0, bad = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    uint32_t hi = __float_as_uint(rows[r * D]), lo = hi;
+#pragma unroll
+    for (int k = 1; k < D; ++k) {
+      const uint32_t w = __float_as_uint(rows[r * D + k]);
+      hi = w > hi ? w : hi;
+      lo = w < lo ? w : lo;
+    }
+    const bool ge = hi < 0x7F800000u;  // every coordinate in [+0, +inf)
+    const bool fl = (lo == fill_bits) && (hi == fill_bits);
+    lmask |= (ge && i0 + r < M) ? (1u << r) : 0u;
+    bad |= (ge || fl) ? 0u : 1u;
+  }
+  if (!active) {
+    lmask = 0;
+    bad = 0;
+  }
+  MaskM gmask;
+  int below;  // live rows of the game below my first row
+  if constexpr (M <= 32) {
+    gmask = q_or(lmask << i0);
+    below = __popc(gmask & ((1u << i0) - 1u));
+  } else {
+    const unsigned long long mm = (unsigned long long)lmask << i0;
+    gmask = ((unsigned long long)q_or((uint32_t)(mm >> 32)) << 32) | q_or((uint32_t)mm);
+    below = __popcll(gmask & ((1ull << i0) - 1ull));
+  }
+  int np = mask_pop(gmask);
+  const bool exact = (fill == pad) && !__any(bad != 0);
+
+  if (!exact) {
+    // ---- slow path (whole wave): the quad's first lane runs the exact generic routines on the image -----------------
+    wave_lds_fence();
+    float* cs = reinterpret_cast<float*>(act) + gi * D;
+    const uint64_t gg = prm.game_offset + (uint64_t)g;
+    PolicyCache pcache;
+    np = leader ? num_points<float>(mine, M, D) : 2;
+    int length = (np < 2) ? 0 : -1;
+    if (prm.count_ws) {
+      const unsigned long long b0 = __ballot(leader && np < 2);
+      if (lane == 0 && b0) count_add(prm.count_ws + blockIdx.x, (uint32_t)__popcll(b0));
+    }
+    for (int t = 0; t < nsteps; ++t) {
+      int axis = -1, cls = 0;
+      uint32_t mask;
+      fast_policy<D>(seed, host_policy, agent_policy, gg, step0 + (uint32_t)t, pcache, cls, axis, mask, 0);
+      if (leader) {
+        for (int k = 0; k < prm.d; ++k) cs[k] = (float)((mask >> k) & 1u);
+        stages_game<float>(mine, prm.m, prm.d, cs, axis, pad, stages, flags);
+        np = num_points<float>(mine, prm.m, prm.d);
+      }
+      const bool done = np < 2;
+      if (done && length < 0) length = t + 1;
+      if (prm.count_ws) {
+        const unsigned long long bd = __ballot(leader && done);
+        if (lane == 0 && bd)
+          count_add(prm.count_ws + (size_t)(t + 1) * prm.count_stride + blockIdx.x, (uint32_t)__popcll(bd));
+      }
+    }
+    if (leader && prm.game_length_out) prm.game_length_out[g] = length;
+    wave_lds_fence();
+    quad_slab_store<M, D>(region, (float*)prm.out + g0 * G::N, ngames, lane);
+    return;
+  }
+
+  // ---- compaction: every live row to the slot of its rank (the compact image lies over the slab image: every lane
+  // holds its rows in registers by now), its index in the game next to it -------------------------------------------------
+  float* cmine = region + gi * (M * CW);
+  uint8_t* tmine = tags + gi * M;
+  {
+    int rank = below;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool live = (lmask >> r) & 1u;
+      if (live) {
+        float* dst = cmine + rank * CW;
+        if constexpr (D == 4) {
+          *reinterpret_cast<vf4*>(dst) = vf4{rows[r * D], rows[r * D + 1], rows[r * D + 2], rows[r * D + 3]};
+        } else if constexpr (D == 3) {
+          *reinterpret_cast<vf4*>(dst) = vf4{rows[r * D], rows[r * D + 1], rows[r * D + 2], 0.0f};
+        } else {
+#pragma unroll
+          for (int k = 0; k < D; ++k) dst[k] = rows[r * D + k];
+        }
+        tmine[rank] = (uint8_t)(i0 + r);
+      }
+      rank += live ? 1 : 0;
+    }
+  }
+  int smax = R;
+#pragma nounroll
+  while (smax > 1 && !__any(np > kQuad * (smax - 1))) --smax;
+  wave_lds_fence();
+
+  // ---- my slots: ranks j, j + 4, ... up to the wave's smax; slots past the game's live rows are holes -------------------
+  float q[R * D];
+  int orig[R];
+#pragma unroll
+  for (int e = 0; e < R * D; ++e) q[e] = INFINITY;
+#pragma unroll
+  for (int s = 0; s < R; ++s) orig[s] = 0;
+  unrolled_while<0, R>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (s >= smax) return false;
+    const bool has = kQuad * s + j < np;
+    const int r = kQuad * s + j < M ? kQuad * s + j : 0;
+    const float* src = cmine + r * CW;
+    if constexpr (D == 4 || D == 3) {
+      const vf4 v = *reinterpret_cast<const vf4*>(src);
+      q[s * D] = has ? v.x : INFINITY;
+      q[s * D + 1] = has ? v.y : INFINITY;
+      q[s * D + 2] = has ? v.z : INFINITY;
+      if constexpr (D == 4) q[s * D + 3] = has ? v.w : INFINITY;
+    } else {
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const float v = src[k];
+        q[s * D + k] = has ? v : INFINITY;
+      }
+    }
+    orig[s] = (int)tmine[r];
+    return true;
+  });
+  wave_lds_fence();
+  if (!active) np = 2;  // never finished, never counted
+  int length = (np < 2) ? 0 : -1;
+
+  // ---- the steps: a staircase of loops, one per bucket of slots per lane ---------------------------------------------
+  int t = 0;
+  bool stop = false;
+  while (t < nsteps && !stop) {  // one pass per window of actions (episodes of up to 24 steps: one pass)
+    if ((uint32_t)((step0 + (uint32_t)t) >> 1) - wb0 >= (uint32_t)kQrBlocks) {
+      wave_lds_fence();
+      wb0 = (step0 + (uint32_t)t) >> 1;
+      const uint32_t nb = wb_last - wb0 + 1u;
+      qr_policy_fill<D>(act, gg0, wb0, (int)(nb < (uint32_t)kQrBlocks ? nb : (uint32_t)kQrBlocks), seed, host_policy,
+                        agent_policy, lane);
+      wave_lds_fence();
+    }
+    const uint32_t wstep0 = wb0 << 1;                       // first step of the window
+    const uint32_t wleft = wstep0 + (uint32_t)kQrSteps - step0;  // steps (from 0) the window reaches
+    const int tw = (wleft < (uint32_t)nsteps) ? (int)wleft : nsteps;
+    const uint8_t* arow = act + gi;
+    QuadLevels<M, D, R>::run([&](auto nbc, auto loc) {
+      constexpr int NB = decltype(nbc)::value, LO = decltype(loc)::value;
+      while (t < tw && (smax > LO || LO == 0) && !stop) {  // (a wave of empty games has smax 1: the last loop's)
+        const uint32_t a = arow[(int)(step0 + (uint32_t)t - wstep0) * kQuadGames];
+        const uint32_t cmask = a & 31u;
+        const int axis = (int)(a >> 5);
+        np = qr_stages<M, CW, R, D, NB>(q, cmask, axis, np, j, flags, stages, cmine, smax);
+        if (!active) np = 2;
+        const bool done = np < 2;
+        if (done && length < 0) length = t + 1;
+        if constexpr (NB == 1) {
+          // Fixed point (hk_duo_kernel.h): once every game of the wave is down to one point at the origin (or none)
+          // nothing changes any more
+          if (t + 1 < nsteps && !__any(active && !done)) {
+            bool still = true;  // (one slot per lane: a row of the game's, a hole, or nothing)
+#pragma unroll
+            for (int k = 0; k < D; ++k) still &= (q[k] == 0.0f);
+            still |= !(q[0] < INFINITY);
+            if (!__any(active && !still)) stop = true;
+          }
+        } else {
+          // re-deal the rows when the widest game of the wave fits fewer slots per lane
+          if (t + 1 < nsteps && !__any(active && np > kQuad * (smax - 1))) {
+            int snew = smax - 1;
+#pragma nounroll
+            while (snew > 1 && !__any(active && np > kQuad * (snew - 1))) --snew;
+            qr_redeal<M, CW, R, D, NB>(q, orig, cmine, tmine, j, active ? np : 0, snew);
+            smax = snew;
+          }
+        }
+        ++t;
+      }
+    });
+  }
+  if (leader && prm.game_length_out) prm.game_length_out[g] = length;
+
+  // ---- publish: padding everywhere, the survivors at their own rows ---------------------------------------------------
+  wave_lds_fence();
+#pragma unroll
+  for (int it = 0; it < G::QL; ++it) {
+    const int qq = lane + it * kWave;
+    if (qq < kQuadGames * G::Q) {
+      if constexpr (G::W == 4) *reinterpret_cast<vf4*>(region + qq * 4) = vf4{pad, pad, pad, pad};
+      else if constexpr (G::W == 2) *reinterpret_cast<vf2*>(region + qq * 2) = vf2{pad, pad};
+      else region[qq] = pad;
+    }
+  }
+  wave_lds_fence();
+  unrolled_while<0, R>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (s >= smax) return false;
+    if (q[s * D] < INFINITY) {
+      float* dst = mine + orig[s] * D;
+      if constexpr (D == 4) {
+        *reinterpret_cast<vf4*>(dst) = vf4{q[s * D], q[s * D + 1], q[s * D + 2], q[s * D + 3]};
+      } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) dst[k] = q[s * D + k];
+      }
+    }
+    return true;
+  });
+  wave_lds_fence();
+  quad_slab_store<M, D>(region, (float*)prm.out + g0 * G::N, ngames, lane);
+  // the finished-game counts: games whose first finished step is <= s, for every s (a finished game stays finished)
+  if (prm.count_ws) {
+    uint32_t* slot = prm.count_ws + blockIdx.x;
+    const uint32_t stride = prm.count_stride;
+#pragma nounroll
+    for (int s = 0; s <= nsteps; ++s) {
+      const unsigned long long b = __ballot(leader && length >= 0 && length <= s);
+      if (lane == 0 && b) count_add(slot + (size_t)s * stride, (uint32_t)__popcll(b));
+    }
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+// plain rollouts (no per-step records, no Zeillinger host, no sorted output) of float32, contiguous, W-aligned records
+inline bool quadroll_request_ok(const Params& prm) {
+  if (prm.mode != kModeRollout || prm.m > 255) return false;
+  if (prm.host_policy == HK_HOST_ZEILLINGER) return false;
+  if (prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out) return false;
+  if ((prm.stages & HK_STAGE_NEWTON) &&
+      ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)))
+    return false;
+  if (prm.flags & (HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_TEAM | HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES |
+                   HK_FLAG_FORCE_POOL))
+    return false;
+  return true;
+}
+
+template <int M, int D>
+int launch_quadroll_t(Params prm, hipStream_t stream) {
+  constexpr int WPB = QuadRollGeom<M, D>::kWpb;
+  const int64_t waves = ((int64_t)prm.batch + kQuadGames - 1) / kQuadGames;
+  const unsigned grid = (unsigned)((waves + WPB - 1) / WPB);
+  prm.games_per_block = kQuadGames * WPB;
+  prm.pad_f32 = (float)prm.pad;
+  launch_prepare();
+  const int hot = fast_hot_config(prm);
+  if (hot == kHotJax)
+    hipLaunchKernelGGL((quadroll_kernel<M, D, kHotJax, WPB>), dim3(grid), dim3(kWave * WPB), 0, stream,
+                       (const float*)prm.in, prm.in_stride, prm.batch, prm);
+  else if (hot == kHotTorch)
+    hipLaunchKernelGGL((quadroll_kernel<M, D, kHotTorch, WPB>), dim3(grid), dim3(kWave * WPB), 0, stream,
+                       (const float*)prm.in, prm.in_stride, prm.batch, prm);
+  else
+    hipLaunchKernelGGL((quadroll_kernel<M, D, kHotNone, WPB>), dim3(grid), dim3(kWave * WPB), 0, stream,
+                       (const float*)prm.in, prm.in_stride, prm.batch, prm);
+  return launch_status();
+}
+
+inline bool quadroll_supported(const Params& prm, int dtype) {
+  if (dtype != HK_F32 || !quadroll_request_ok(prm)) return false;
+#define HK_X(M_, D_) if (prm.m == M_ && prm.d == D_) return quad_ok_t<M_, D_>(prm);
+  HK_QUAD_SPECS(HK_X)
+#undef HK_X
+  return false;
+}
+
+// where this kernel is the default: the shapes without a two-lane kernel ((50,4): hk::team_kernel's rollouts before)
+inline bool quadroll_default(const Params& prm, int simds) {
+  (void)simds;
+  return prm.m > 32;
+}
+
+// workgroups of a launch (the finished-game workspace has one slot per workgroup and step)
+inline int64_t quadroll_grid(const Params& prm) {
+#define HK_X(M_, D_)                                                             \
+  if (prm.m == M_ && prm.d == D_) {                                               \
+    constexpr int WPB = QuadRollGeom<M_, D_>::kWpb;                               \
+    return (((int64_t)prm.batch + kQuadGames - 1) / kQuadGames + WPB - 1) / WPB;  \
+  }
+  HK_QUAD_SPECS(HK_X)
+#undef HK_X
+  return 0;
+}
+
+#ifndef HK_SPEC_TU
+#define HK_X(M_, D_) extern template int launch_quadroll_t<M_, D_>(Params, hipStream_t);
+HK_QUAD_SPECS(HK_X)
+#undef HK_X
+
+inline int launch_quadroll(const Params& prm, hipStream_t stream) {
+#define HK_X(M_, D_) if (prm.m == M_ && prm.d == D_) return launch_quadroll_t<M_, D_>(prm, stream);
+  HK_QUAD_SPECS(HK_X)
+#undef HK_X
+  return HK_ERR_UNSUPPORTED;
+}
+#endif
+
+}  // namespace hk

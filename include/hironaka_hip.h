@@ -115,6 +115,9 @@ extern "C" {
 #define HK_FLAG_FORCE_TWO_LANES 512u    /* testing / tuning: two lanes per game (hk::duo_kernel) at any batch size */
 #define HK_FLAG_FORCE_FOUR_LANES 1024u  /* testing / tuning: four lanes per game (hk::quad_kernel) for every hk_step
                                          * it can serve, at any batch size                                       */
+#define HK_FLAG_FORCE_POOL 2048u        /* testing / tuning: hk_rollout on the pool kernel (hk::pool_kernel: 256 games per
+                                         * workgroup, live games re-dealt to the waves between steps) for every
+                                         * rollout it can serve, at any batch size                                  */
 #define HK_FLAG_DEFER_COUNTS 128u       /* hk_rollout: leave the finished-game counts as partial
                                            sums in `workspace` (they accumulate over launches);
                                            hk_rollout_reduce_counts adds them to done_count     */

@@ -14,7 +14,8 @@ Q = torch.empty_like(P)
 for rep in range(3):
     res = ops.rollout(Q, T, 1 + rep, initial=P, record=("game_length",))
 torch.cuda.synchronize()
-gl = res["game_length"].cpu().numpy().reshape(-1, 32)[:, :8].astype(np.int64)
+full = res["game_length"].cpu().numpy().reshape(-1, 32).astype(np.int64)
+gl = full[:, :8]
 t0, t1, t2, t3, steps, smax, blk, hwid = (gl[:, i] for i in range(8))
 base = t0.min()
 us = lambda x: ((x - base) & 0xFFFFFFFF) / 100.0  # 100 MHz constant clock
@@ -33,3 +34,20 @@ late = np.argsort(us(t3))[-10:]
 print("the ten last waves: block, start, slab, loop done, end, steps, smax")
 for i in late:
     print(f"  {blk[i]:5d} {us(t0)[i]:6.2f} {us(t1)[i]:6.2f} {us(t2)[i]:6.2f} {us(t3)[i]:6.2f} {steps[i]:3d} {smax[i]:2d}")
+
+# per-step stamps (probe build): time of each step and the slots per lane after it
+st = full[:, 8:28] & 0xFFFFFFFF
+clk = (st >> 4); sm = st & 15
+t1m = (t1 & 0x0FFFFFFF)
+print("step: mean duration [us] over the waves that ran it / mean slots per lane after it / share of waves whose slots shrank (re-deal)")
+prev = t1m
+prev_s = smax
+for k in range(20):
+    ran = steps > k
+    if ran.sum() == 0:
+        break
+    dt = ((clk[:, k] - prev) & 0x0FFFFFFF) / 100.0
+    shr = (sm[:, k] < prev_s) & ran
+    print(f"  step {k:2d}: waves {ran.sum():5d}  mean {dt[ran].mean():6.3f}  with re-deal {dt[shr].mean() if shr.sum() else 0:6.3f} (n={shr.sum()})  without {dt[ran & ~shr].mean() if (ran & ~shr).sum() else 0:6.3f}  slots after {sm[ran, k].mean():.2f}")
+    prev = np.where(ran, clk[:, k], prev)
+    prev_s = np.where(ran, sm[:, k], prev_s)

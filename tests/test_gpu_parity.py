@@ -434,13 +434,85 @@ def test_compiled_rollout_configurations_match_oracle(spec):
         for T in (1, 20):
             want_p, want = CO.rollout(p0, T, 31, game_offset=5, host_policy=A.HK_HOST_RANDOM, agent_policy=ap,
                                       stages=stages, flags=flags_o, record=False)
-            for lanes in (0, A.HK_FLAG_FORCE_ONE_LANE):  # hk::duo_kernel / hk::fast_kernel (where both exist)
+            # hk::duo_kernel / hk::fast_kernel / hk::pool_kernel (where they exist; elsewhere the flags change nothing)
+            for lanes in (0, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_POOL, A.HK_FLAG_FORCE_FOUR_LANES):
                 P = dev(p0.copy())
                 got = ops.rollout(P, T, 31, game_offset=5, host_policy=A.HK_HOST_RANDOM, agent_policy=ap,
                                   stages=stages, flags=flags_p | lanes, record=("game_length",))
                 assert np.array_equal(host(P), want_p), (flags_p, T, lanes)
                 assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"]), (flags_p, T)
                 assert np.array_equal(host(got["game_length"]), want["game_length"]), (flags_p, T, lanes)
+
+
+@pytest.mark.parametrize("family,spec", [("pool", s) for s in ((20, 3), (10, 3), (5, 3), (16, 3), (8, 4), (20, 4))] +
+                         [("quad", s) for s in ((20, 3), (10, 3), (20, 4), (50, 4))])
+def test_forced_rollout_families_match_oracle(family, spec):
+    """hk::pool_kernel (256 games per workgroup, live games re-dealt to the waves between rounds of steps) and
+    hk::quadroll_kernel (four lanes per game, decoded action windows of 24 steps) against the oracle: episode lengths
+    on both sides of every round / window boundary, a step offset that is not a multiple of a Philox block, batches
+    that leave waves / workgroups partly or wholly empty, the run-time configured variant (other policies, rescale, no
+    reposition), a padding value that sends a workgroup down the exact generic path, and non-canonical games in one
+    workgroup only"""
+    m, d = spec
+    force = A.HK_FLAG_FORCE_POOL if family == "pool" else A.HK_FLAG_FORCE_FOUR_LANES
+    stages = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON
+    torch_flags = ops.make_flags("torch", noop_if_invalid=True, ignore_ended=True)
+    torch_flags_o = CO.flags_of(sem="torch", noop_if_invalid=True, ignore_ended=True)
+    cases = []
+    for T in (0, 1, 2, 3, 4, 5, 6, 8, 9, 12, 13, 20, 24, 25, 41, 49):
+        cases.append(dict(b=700, T=T, so=0, fp=0, fo=0, hp=A.HK_HOST_RANDOM, ap=A.HK_AGENT_RANDOM, st=stages, pad=-1.0))
+    for b in (1, 31, 33, 255, 257, 513, 1500):
+        cases.append(dict(b=b, T=20, so=3, fp=0, fo=0, hp=A.HK_HOST_RANDOM, ap=A.HK_AGENT_RANDOM, st=stages, pad=-1.0))
+    cases.append(dict(b=900, T=20, so=5, fp=torch_flags, fo=torch_flags_o, hp=A.HK_HOST_RANDOM,
+                      ap=A.HK_AGENT_RANDOM_LEGAL, st=stages, pad=-1.0))
+    for hp, ap, st in ((A.HK_HOST_ALL_COORD, A.HK_AGENT_CHOOSE_FIRST, stages),
+                       (A.HK_HOST_RANDOM, A.HK_AGENT_CHOOSE_LAST, stages | A.HK_STAGE_RESCALE),
+                       (A.HK_HOST_RANDOM, A.HK_AGENT_RANDOM, A.HK_STAGE_SHIFT | A.HK_STAGE_NEWTON),
+                       (A.HK_HOST_RANDOM, A.HK_AGENT_RANDOM_LEGAL, A.HK_STAGE_SHIFT)):
+        cases.append(dict(b=600, T=11, so=2, fp=0, fo=0, hp=hp, ap=ap, st=st, pad=-1.0))
+    cases.append(dict(b=600, T=9, so=0, fp=ops.make_flags("torch"), fo=CO.flags_of(sem="torch"), hp=A.HK_HOST_RANDOM,
+                      ap=A.HK_AGENT_RANDOM, st=stages, pad=-2.5))
+    cases.append(dict(b=600, T=9, so=0, fp=0, fo=0, hp=A.HK_HOST_RANDOM, ap=A.HK_AGENT_RANDOM, st=stages, pad=-2.5))
+    cases.append(dict(b=600, T=9, so=1, fp=0, fo=0, hp=A.HK_HOST_RANDOM, ap=A.HK_AGENT_RANDOM, st=stages, pad=-1.0,
+                      poison=True))
+    for i, c in enumerate(cases):
+        p0 = CO.generate_points(c["b"], m, d, 20, 11 + i, padding_value=c["pad"],
+                                flags=c["fo"] & 3)
+        if c.get("poison"):  # non-canonical games (a negative coordinate in a live row) in the second workgroup only
+            p0[300:310, 0, 0] = -0.5
+        want_p, want = CO.rollout(p0, c["T"], 77, game_offset=9, step_offset=c["so"], host_policy=c["hp"],
+                                  agent_policy=c["ap"], stages=c["st"], flags=c["fo"], padding_value=c["pad"],
+                                  record=False)
+        P = dev(p0.copy())
+        got = ops.rollout(P, c["T"], 77, game_offset=9, step_offset=c["so"], host_policy=c["hp"], agent_policy=c["ap"],
+                          stages=c["st"], flags=c["fp"] | force, padding_value=c["pad"],
+                          record=("game_length",))
+        assert np.array_equal(host(P), want_p), c
+        assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"]), c
+        assert np.array_equal(host(got["game_length"]), want["game_length"]), c
+
+
+def test_pool_equals_fixed_deal_at_baseline_size():
+    """BASELINE configs[1] at size: the pool kernel and the two-lane kernel leave identical states, finished-game
+    histograms and game lengths (with and without a separate initial state), and deferred counts of launches of both
+    families meet in one workspace"""
+    b = 65536
+    fresh = ops.generate_points(b, 20, 3, 20, seed=42)
+    A1, A2 = torch.empty_like(fresh), torch.empty_like(fresh)
+    r1 = ops.rollout(A1, 20, 7, initial=fresh, flags=A.HK_FLAG_FORCE_TWO_LANES, record=("game_length",))
+    r2 = ops.rollout(A2, 20, 7, initial=fresh, flags=A.HK_FLAG_FORCE_POOL, record=("game_length",))
+    assert torch.equal(A1, A2)
+    assert torch.equal(r1["done_count"], r2["done_count"])
+    assert torch.equal(r1["game_length"], r2["game_length"])
+    B2 = fresh.clone()
+    ops.rollout(B2, 20, 7, flags=A.HK_FLAG_FORCE_POOL)
+    assert torch.equal(A1, B2)
+    ws = ops.rollout_workspace(b, 20, (20, 3))
+    dc = torch.zeros(21, dtype=torch.int64, device="cuda")
+    ops.rollout(A1, 20, 7, initial=fresh, flags=A.HK_FLAG_FORCE_TWO_LANES, defer_counts=True, workspace=ws)
+    ops.rollout(A2, 20, 7, initial=fresh, flags=A.HK_FLAG_FORCE_POOL, defer_counts=True, workspace=ws)
+    ops.reduce_counts(ws, dc, b, 20, (20, 3))
+    assert torch.equal(dc, 2 * r1["done_count"].to(torch.int64))
 
 
 def test_rollout_equals_stepwise_launches():
