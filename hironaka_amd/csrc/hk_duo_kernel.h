@@ -399,22 +399,33 @@ __device__ inline void duo_policy_words(uint64_t gg, uint32_t step, uint64_t see
 // instructions and most of a late step's latency (a step on one slot per lane is ~40 instructions without it).  The
 // words depend on (game, step) only, not on the state: a WINDOW of kDuoPreBlocks blocks per game (24 steps) is
 // computed before the first step -- while the wave would otherwise only wait for its slab -- two independent chains at
-// a time, and parked in LDS as [block][game] x 16 B; a step reads its two words with one ds_read_b64 (both lanes of a
-// pair the same address).  Episodes longer than a window refill it between two passes over the staircase.
+// a time, DECODED (subset mask, axis: the decode was another ~15 instructions of every step) and parked in LDS, one byte
+// per game and step; a step reads its byte (both lanes of a pair the same address).  Episodes longer than a window
+// refill it between two passes over the staircase.
 constexpr int kDuoPreBlocks = 12;
 
-// blocks [wb0, wb0 + nb) of the wave's games: lane (gi, h) computes blocks wb0 + h, wb0 + h + 2, ...
-__device__ __forceinline__ void duo_policy_fill(uint32_t* pol, uint64_t gg, uint32_t wb0, int nb, uint64_t seed, int gi,
-                                                int h) {
+// blocks [wb0, wb0 + nb) of the wave's games: lane (gi, h) computes blocks wb0 + h, wb0 + h + 2, ... and stores the
+// DECODED actions of their steps, one byte per game and step: subset mask (D bits) | axis << 5
+template <int D>
+__device__ __forceinline__ void duo_policy_fill(uint8_t* act, uint64_t gg, uint32_t wb0, int nb, uint64_t seed,
+                                                int host_policy, int agent_policy, int gi, int h) {
+  static_assert(D <= 5, "an action travels as a byte");
 #pragma nounroll
   for (int i = 0; i < kDuoPreBlocks; i += 4) {
     if (i >= nb) break;  // wave-uniform
-    const uint32_t b0 = (uint32_t)(i + h), b1 = b0 + 2u;
-    const U4 r0 = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), wb0 + b0, kStreamPolicy, seed);
-    const U4 r1 = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), wb0 + b1, kStreamPolicy, seed);
-    typedef uint32_t vu4 __attribute__((ext_vector_type(4)));
-    *reinterpret_cast<vu4*>(pol + ((int)b0 * kDuoGames + gi) * 4) = vu4{r0.x, r0.y, r0.z, r0.w};
-    *reinterpret_cast<vu4*>(pol + ((int)b1 * kDuoGames + gi) * 4) = vu4{r1.x, r1.y, r1.z, r1.w};
+    const int b0 = i + h, b1 = b0 + 2;
+    const U4 r0 = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), wb0 + (uint32_t)b0, kStreamPolicy, seed);
+    const U4 r1 = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), wb0 + (uint32_t)b1, kStreamPolicy, seed);
+    int cls, axis;
+    uint32_t mask;
+    policy_from_words<D>(r0.x, r0.y, host_policy, agent_policy, cls, axis, mask, 0);
+    act[(2 * b0) * kDuoGames + gi] = (uint8_t)(mask | ((uint32_t)axis << 5));
+    policy_from_words<D>(r0.z, r0.w, host_policy, agent_policy, cls, axis, mask, 0);
+    act[(2 * b0 + 1) * kDuoGames + gi] = (uint8_t)(mask | ((uint32_t)axis << 5));
+    policy_from_words<D>(r1.x, r1.y, host_policy, agent_policy, cls, axis, mask, 0);
+    act[(2 * b1) * kDuoGames + gi] = (uint8_t)(mask | ((uint32_t)axis << 5));
+    policy_from_words<D>(r1.z, r1.w, host_policy, agent_policy, cls, axis, mask, 0);
+    act[(2 * b1 + 1) * kDuoGames + gi] = (uint8_t)(mask | ((uint32_t)axis << 5));
   }
 }
 
@@ -431,7 +442,7 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   __shared__ __align__(16) float lds[kDuoGames * G::S];
   __shared__ float cbuf[kDuoGames * D];  // slow path only
   // plain rollouts: the policy words of a window of steps (duo_policy_fill)
-  __shared__ __align__(16) uint32_t pol[(MODE == kModeRollout) ? kDuoPreBlocks * kDuoGames * 4 : 4];
+  __shared__ __align__(16) uint8_t pol[(MODE == kModeRollout) ? 2 * kDuoPreBlocks * kDuoGames : 16];
   const int lane = threadIdx.x;
   const int h = lane & 1, gi = lane >> 1;
   const int64_t g0 = (int64_t)blockIdx.x * kDuoGames;
@@ -455,7 +466,10 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   const uint32_t pol_last = (prm.steps > 0) ? (prm.step_offset + (uint32_t)prm.steps - 1u) >> 1 : pol_b0;
   if constexpr (MODE == kModeRollout) {
     const uint32_t nb = pol_last - pol_b0 + 1u;
-    duo_policy_fill(pol, gg, pol_b0, (int)(nb < (uint32_t)kDuoPreBlocks ? nb : (uint32_t)kDuoPreBlocks), prm.seed, gi, h);
+    duo_policy_fill<D>(pol, gg, pol_b0, (int)(nb < (uint32_t)kDuoPreBlocks ? nb : (uint32_t)kDuoPreBlocks), prm.seed,
+                       HOT ? (int)HK_HOST_RANDOM : prm.host_policy,
+                       (HOT == kHotJax) ? (int)HK_AGENT_RANDOM
+                                        : (HOT == kHotTorch) ? (int)HK_AGENT_RANDOM_LEGAL : prm.agent_policy, gi, h);
   }
   float* mine = lds + gi * G::S;
   const float pad = (float)prm.pad;
@@ -591,7 +605,8 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
       __syncthreads();
       pol_b0 = (step0 + (uint32_t)t) >> 1;
       const uint32_t nb = pol_last - pol_b0 + 1u;
-      duo_policy_fill(pol, gg, pol_b0, (int)(nb < (uint32_t)kDuoPreBlocks ? nb : (uint32_t)kDuoPreBlocks), seed, gi, h);
+      duo_policy_fill<D>(pol, gg, pol_b0, (int)(nb < (uint32_t)kDuoPreBlocks ? nb : (uint32_t)kDuoPreBlocks), seed,
+                         host_policy, agent_policy, gi, h);
       __syncthreads();
     }
     // last step (exclusive) the window covers
@@ -599,39 +614,47 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
     const int tw = (wend_abs - step0 < (uint32_t)nsteps) ? (int)(wend_abs - step0) : nsteps;
     DuoLevels<CH>::run([&](auto nbc, auto loc) {
       constexpr int NB = decltype(nbc)::value, LO = decltype(loc)::value;
+#ifndef HK_NO_SETPRIO
+      // The launch ends with its slowest waves -- the ones that start in a wide bucket or run many steps -- and the two
+      // waves of a SIMD share its issue slots by priority, then age: a wave in a wide bucket outranks its neighbour
+      // (who is ahead anyway), and so does one that is still running late in the episode.
+      if ((smax > LO || LO == 0) && t < tw && !stop) {
+        if (t >= 10) __builtin_amdgcn_s_setprio(3);
+        else if constexpr (NB >= 6) __builtin_amdgcn_s_setprio(3);
+        else if constexpr (NB >= 4) __builtin_amdgcn_s_setprio(2);
+        else if constexpr (NB >= 2) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      }
+#endif
       while (t < tw && (smax > LO || LO == 0) && !stop) {  // (a wave of empty games has smax 0: the last loop's)
-        int axis, cls;
-        uint32_t mask;
-        const uint32_t step = step0 + (uint32_t)t;
-        typedef uint32_t vu2 __attribute__((ext_vector_type(2)));
-        const vu2 pw = *reinterpret_cast<const vu2*>(pol + ((int)((step >> 1) - pol_b0) * kDuoGames + gi) * 4 + (step & 1u) * 2u);
-        const uint32_t ra = pw.x, rb = pw.y;
-        policy_from_words<D>(ra, rb, host_policy, agent_policy, cls, axis, mask, 0);
+#ifndef HK_NO_SETPRIO
+        if constexpr (NB == 1) {
+          if (t == 10) __builtin_amdgcn_s_setprio(3);
+        }
+#endif
+        const uint32_t a = pol[(int)(step0 + (uint32_t)t - (pol_b0 << 1)) * kDuoGames + gi];
+        const uint32_t mask = a & 31u;
+        const int axis = (int)(a >> 5);
         const unsigned st = (end_sort && t + 1 == nsteps) ? (stages & ~(unsigned)HK_STAGE_RESCALE) : stages;
         rescale_pending = end_sort && t + 1 == nsteps && (stages & HK_STAGE_RESCALE);
         np = d_stages<CH, D, NB, true>(q, c, axis, np, h, flags, st, mask);
         if (!active) np = 2;
         const bool done = np < 2;
         if (done && length < 0) length = t + 1;
-        const unsigned long long bd = __ballot(leader && done);
-        if (count_slot && lane == 0) count_add(count_slot + (size_t)(t + 1) * count_stride, (uint32_t)__popcll(bd));
+        // (the finished-game counts: ballots over the games' first finished steps after the loop -- a finished game
+        // stays finished --, not an atomic per step in here)
         if constexpr (NB == 1) {
           // Fixed point: a game that is down to ONE point sitting at the origin (or to none) does not change any
           // more -- whatever the subset and the axis: the shift adds zeros, reposition / rescale find nothing to move,
           // the Newton stage has nothing to compare.  Once every game of the wave is there (a game reaches it one
           // step after it ends when reposition is on; the mean game lasts 5 steps, the longest of 32 about 13), the
-          // rest of the episode is the finished-game counts, added in closed form.
-          if (bd == __ballot(leader) && t + 1 < nsteps) {
+          // rest of the episode changes nothing.
+          if (t + 1 < nsteps && !__any(active && !done)) {
             bool still = true;  // (one slot per lane: it holds the game's point, a hole, or nothing)
 #pragma unroll
             for (int k = 0; k < D; ++k) still &= (q[k] == 0.0f);
             still |= !(q[0] < INFINITY);
-            if (!__any(active && !still)) {
-              if (count_slot && lane == 0)
-                for (int tt = t + 1; tt < nsteps; ++tt)
-                  count_add(count_slot + (size_t)(tt + 1) * count_stride, (uint32_t)__popcll(bd));
-              stop = true;
-            }
+            if (!__any(active && !still)) stop = true;
           }
         } else {
           // re-deal the rows when the widest game of the wave fits fewer slots per lane
@@ -656,6 +679,13 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
     probe_steps = t;
     probe_t2 = wall_clock64();
 #endif
+    if (count_slot) {  // games whose first finished step is <= s, for every step s >= 1 (s = 0 was counted at entry)
+#pragma nounroll
+      for (int sidx = 1; sidx <= nsteps; ++sidx) {
+        const unsigned long long bf = __ballot(leader && length >= 0 && length <= sidx);
+        if (lane == 0 && bf) count_add(count_slot + (size_t)sidx * count_stride, (uint32_t)__popcll(bf));
+      }
+    }
   }
   const bool want_obs = kRec && prm.obs_out != nullptr;
   const bool want_records = kRec && (prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out);

@@ -411,6 +411,8 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
     const uint8_t* arow = act + gi;
     QuadLevels<M, D, R>::run([&](auto nbc, auto loc) {
       constexpr int NB = decltype(nbc)::value, LO = decltype(loc)::value;
+      // (no s_setprio by bucket here: with three or four waves per SIMD it starves the others -- measured 24.4 -> 26.5 us
+      // at (20,3) x 65 536, 192 -> 202 us at (50,4) x 262 144; hk_duo_kernel.h, two waves per SIMD, gains 3 % from it)
       while (t < tw && (smax > LO || LO == 0) && !stop) {  // (a wave of empty games has smax 1: the last loop's)
         const uint32_t a = arow[(int)(step0 + (uint32_t)t - wstep0) * kQuadGames];
         const uint32_t cmask = a & 31u;
@@ -530,9 +532,12 @@ inline bool quadroll_supported(const Params& prm, int dtype) {
 }
 
 // where this kernel is the default: the shapes without a two-lane kernel ((50,4): hk::team_kernel's rollouts before)
+// ... and, on the small shapes, batches of up to two of its waves per SIMD (32 768 games on an MI355X): measured
+// (scripts/probe_pool.py, (20,3)): 14.0 / 15.0 / 17.4 us per 20-step episode at 4 096 / 16 384 / 32 768 games against
+// 16.9 / 18.3 / 18.8 on two lanes per game, 24.5 against 22.2 at 65 536
 inline bool quadroll_default(const Params& prm, int simds) {
-  (void)simds;
-  return prm.m > 32;
+  if (prm.m > 32) return true;
+  return ((int64_t)prm.batch + kQuadGames - 1) / kQuadGames <= (int64_t)2 * simds;
 }
 
 // workgroups of a launch (the finished-game workspace has one slot per workgroup and step)
