@@ -587,7 +587,7 @@ int hk_search_expand_scatter_agent(const void* points, const void* feat, const v
   if (st != HK_OK) return st;
   if (num_classes < 1 || (int64_t)num_classes > ((int64_t)1 << dim) - dim - 1) return HK_ERR_SHAPE;
   if (batch == 0) return HK_OK;
-  if (!points || !feat || !host_logits || !node || !embeddings || !features || !agent_feat_out) return HK_ERR_NULL;
+  if (!points || !feat || !host_logits || !node || !embeddings || !agent_feat_out) return HK_ERR_NULL;
   if (!aligned(points, 4) || !aligned(feat, 4) || !aligned(host_logits, 4) || !aligned(node, 4) ||
       !aligned(embeddings, 4) || !aligned(features, 4) || !aligned(agent_feat_out, 4) || !aligned(class_out, 4))
     return HK_ERR_ALIGN;

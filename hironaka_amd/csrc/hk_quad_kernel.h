@@ -783,9 +783,18 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void 
       if (prm.prev_done_out) prm.prev_done_out[g] = prev_done;
       if (prm.reward_out) prm.reward_out[g] = prm.reward_sign * (float)(done && !prev_done);
       if (prm.num_points_out) prm.num_points_out[g] = np;
+      if constexpr (FEAT) {
+        // hk_step_features: the observation features of the result by the generic routines too (jax/util.py:172-214:
+        // [rescale] + rows in descending key order), built in the game's part of the compact region
+        float* f = compact + gi * G::N;
+        for (int e = 0; e < G::N; ++e) f[e] = mine[e];
+        stages_game<float>(f, M, D, cs, -1, pad, (prm.feat_scale ? (unsigned)HK_STAGE_RESCALE : 0u) | kStageFeatureSort,
+                           (unsigned)HK_SEM_JAX);
+      }
     }
     wave_lds_fence();
     quad_slab_store<M, D>(image, (float*)prm.out + g0 * G::N, ngames, lane);
+    if constexpr (FEAT) quad_slab_store<M, D>(compact, prm.feat_out + g0 * G::N, ngames, lane);
     return;
   }
 

@@ -490,7 +490,7 @@ __global__ void expand_scatter_agent_kernel(const float* points, const float* fe
     if (inside) emb[erow + e] = points[(int64_t)g * E + e];
   } else if (e < 2 * E) {
     const float v = feat_in[(int64_t)g * E + (e - E)];
-    if (inside) feat[frow + (e - E)] = v;
+    if (inside && feat) feat[frow + (e - E)] = v;  // (feat == NULL: the caller keeps no per-node features)
     agent_feat_out[(int64_t)g * (E + d) + (e - E)] = v;
   } else {
     const int k = e - 2 * E;

@@ -38,22 +38,39 @@ def shard_range(total_games: int, rank_: Optional[int] = None, world_: Optional[
     return Shard(start, size, total_games)
 
 
-def all_gather_games(local: torch.Tensor, shard: Optional[Shard] = None, direct: bool = False) -> torch.Tensor:
-    """[B_local, ...] per rank -> [B_total, ...] on every rank, in global game order.  Equal shards use
-    one all_gather_into_tensor; ragged shards are padded to the largest one first.  Without a `shard` the
-    ranks first exchange their local sizes (one tiny all-gather), so ragged inputs take the padded path
-    instead of failing inside the collective."""
+def _agree(ok: bool, device, what: str) -> None:
+    """raise on EVERY rank if any rank found its input inconsistent (one tiny all-reduce): a rank that raised alone
+    would leave the others waiting inside the collective that follows"""
+    flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()):
+        raise ValueError(what if not ok else "another rank's local batch does not match its shard")
+
+
+def all_gather_games(local: torch.Tensor, shard: Optional[Shard] = None, direct: bool = False,
+                     rows_per_game: int = 1, validate: bool = True) -> torch.Tensor:
+    """[B_local * rows_per_game, ...] per rank -> [B_total * rows_per_game, ...] on every rank, in global game order
+    (rows_per_game > 1: a rollout flattened to one row per game and move).  Equal shards use one
+    all_gather_into_tensor; ragged shards are padded to the largest one first.
+    With a `shard` the local size is checked against it -- collectively (`validate`: one int32 all-reduce, a host
+    synchronisation; pass validate=False inside timed or captured code).  Without a `shard` the ranks first exchange
+    their local sizes (one tiny all-gather and a host synchronisation as well)."""
     w = world()
     if w == 1:
         return local
+    k = int(rows_per_game)
     if direct:
         if shard is None:
             raise ValueError("the direct gather needs the Shard (every rank must know every shard's size)")
-        return all_gather_games_direct(local, shard)
+        return all_gather_games_direct(local, shard, rows_per_game=k, validate=validate)
     if shard is not None:
-        sizes = [shard_range(shard.total, r, w).size for r in range(w)]
-        if sizes[rank()] != local.shape[0]:
-            raise ValueError(f"rank {rank()} holds {local.shape[0]} games, its shard of {shard.total} is {sizes[rank()]}")
+        sizes = [shard_range(shard.total, r, w).size * k for r in range(w)]
+        ok = sizes[rank()] == local.shape[0]
+        what = f"rank {rank()} holds {local.shape[0]} rows, its shard of {shard.total} games is {sizes[rank()]}"
+        if validate:
+            _agree(ok, local.device, what)
+        elif not ok:
+            raise ValueError(what)
     else:
         mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
         every = torch.empty(w, dtype=torch.int64, device=local.device)
@@ -71,7 +88,8 @@ def all_gather_games(local: torch.Tensor, shard: Optional[Shard] = None, direct:
     return torch.cat([out[r * biggest: r * biggest + sizes[r]] for r in range(w)], dim=0)
 
 
-def all_gather_games_direct(local: torch.Tensor, shard: Shard) -> torch.Tensor:
+def all_gather_games_direct(local: torch.Tensor, shard: Shard, rows_per_game: int = 1,
+                            validate: bool = True) -> torch.Tensor:
     """The same gather as FULLY-CONNECTED point-to-point transfers: every rank posts one send of its shard to and one
     receive from every other rank in ONE batch (`dist.batch_isend_irecv` = a grouped send/recv in RCCL), i.e. the 7
     xGMI links of an MI355X carry 7 shards concurrently instead of a ring forwarding them hop by hop (SURVEY.md
@@ -81,12 +99,17 @@ def all_gather_games_direct(local: torch.Tensor, shard: Shard) -> torch.Tensor:
     w, r = world(), rank()
     if w == 1:
         return local
-    sizes = [shard_range(shard.total, k, w).size for k in range(w)]
-    starts = [shard_range(shard.total, k, w).start for k in range(w)]
-    if sizes[r] != local.shape[0]:
-        raise ValueError(f"rank {r} holds {local.shape[0]} games, its shard of {shard.total} is {sizes[r]}")
+    rpg = int(rows_per_game)
+    sizes = [shard_range(shard.total, k, w).size * rpg for k in range(w)]
+    starts = [shard_range(shard.total, k, w).start * rpg for k in range(w)]
+    ok = sizes[r] == local.shape[0]
+    what = f"rank {r} holds {local.shape[0]} rows, its shard of {shard.total} games is {sizes[r]}"
+    if validate:
+        _agree(ok, local.device, what)
+    elif not ok:
+        raise ValueError(what)
     local = local.contiguous()
-    out = torch.empty((shard.total, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    out = torch.empty((shard.total * rpg, *local.shape[1:]), dtype=local.dtype, device=local.device)
     out[starts[r]: starts[r] + sizes[r]] = local
     ops = []
     for k in range(w):
@@ -103,9 +126,10 @@ def all_gather_games_direct(local: torch.Tensor, shard: Shard) -> torch.Tensor:
     return out
 
 
-def all_gather_rollout(rollout: Sequence[torch.Tensor], shard: Optional[Shard] = None):
-    """(obs, policy, value) of each rank -> the full batch on every rank (trainer boundary)."""
-    return tuple(all_gather_games(x, shard) for x in rollout)
+def all_gather_rollout(rollout: Sequence[torch.Tensor], shard: Optional[Shard] = None, rows_per_game: int = 1):
+    """(obs, policy, value) of each rank -> the full batch on every rank (trainer boundary).  `rows_per_game`:
+    simulate()'s tensors are flattened to one row per game and move ([B * T, ...]: T rows per game)."""
+    return tuple(all_gather_games(x, shard, rows_per_game=rows_per_game) for x in rollout)
 
 
 def all_reduce_counts(counts: torch.Tensor) -> torch.Tensor:

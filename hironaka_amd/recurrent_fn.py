@@ -164,10 +164,9 @@ class AgentExpander:
         b, n, width = tree.embeddings.shape
         e, d = self.m * self.d, self.d
         dev = tree.embeddings.device
-        features = torch.zeros((b, n, e), dtype=torch.float32, device=dev)
-        features[:, 0] = ops.get_features(root_embedding.contiguous(), self.scale_observation, spec=(self.m, self.d))
-        return {"features": features,
-                "points": torch.empty((b, e), dtype=torch.float32, device=dev),
+        # (no per-node features table here: an agent-role expansion never reads a node's features again -- the gather
+        # takes the embeddings only and the agent network's input is built from `feat` -- so the scatter gets NULL)
+        return {"points": torch.empty((b, e), dtype=torch.float32, device=dev),
                 "coords": torch.empty((b, d), dtype=torch.float32, device=dev),
                 "agent_feat": torch.empty((b, e + d), dtype=torch.float32, device=dev),
                 "cls": torch.empty(b, dtype=torch.int32, device=dev),
@@ -186,7 +185,6 @@ class AgentExpander:
         L = lib()
         stream = C.c_void_p(torch.cuda.current_stream(tree.embeddings.device).cuda_stream)
         points, coords, agent_feat, cls = state["points"], state["coords"], state["agent_feat"], state["cls"]
-        features = state["features"]
         check(L.hk_search_expand_gather_agent(tree.embeddings.data_ptr(), parent.data_ptr(), points.data_ptr(),
                                               coords.data_ptr(), b, n, m, d, stream), "hk_search_expand_gather_agent")
         want = ("done", "prev_done", "reward")
@@ -213,7 +211,7 @@ class AgentExpander:
         host_logits, _ = self.host_model(feat, host_params)
         host_logits = host_logits.to(torch.float32).contiguous()
         check(L.hk_search_expand_scatter_agent(updated.data_ptr(), feat.data_ptr(), host_logits.data_ptr(),
-                                               node.data_ptr(), tree.embeddings.data_ptr(), features.data_ptr(),
+                                               node.data_ptr(), tree.embeddings.data_ptr(), None,
                                                agent_feat.data_ptr(), cls.data_ptr(), b, n, m, d,
                                                host_logits.shape[1], stream), "hk_search_expand_scatter_agent")
         logits, value = self.agent_model(agent_feat, agent_params)

@@ -59,14 +59,18 @@ def get_evaluation_loop(role: str, policy_fn: Callable, opponent_fn: Callable, r
         root = RootFnOutput(prior_logits=policy_prior, value=value_prior, embedding=root_states)
         key, subkey = _split(key)
         if use_graph:
-            sig = (tuple(root_states.shape), root_states.dtype, root_states.device, invalid_actions is not None,
-                   id(role_fn_args), id(opponent_fn_args))
-            if sig not in captured:
-                captured[sig] = CapturedSearch((role_fn_args, opponent_fn_args), subkey, root, recurrent_fn,
-                                               num_evaluations, invalid_actions, max_depth,
-                                               max_num_considered_actions=max_num_considered_actions,
-                                               gumbel_scale=gumbel_scale)
-            return captured[sig](subkey, root, invalid_actions)
+            # one capture per launch shape; it is tied to the identity of the argument tuples (a hipGraph replays with
+            # the tensors it was captured with): other tuples REPLACE it -- no unbounded growth when a trainer hands
+            # over fresh parameter objects every optimiser step (updating the parameter tensors in place keeps it)
+            sig = (tuple(root_states.shape), root_states.dtype, root_states.device, invalid_actions is not None)
+            ids = (id(role_fn_args), id(opponent_fn_args))
+            if sig not in captured or captured[sig][0] != ids:
+                captured.pop(sig, None)
+                captured[sig] = (ids, CapturedSearch((role_fn_args, opponent_fn_args), subkey, root, recurrent_fn,
+                                                     num_evaluations, invalid_actions, max_depth,
+                                                     max_num_considered_actions=max_num_considered_actions,
+                                                     gumbel_scale=gumbel_scale), (role_fn_args, opponent_fn_args))
+            return captured[sig][1](subkey, root, invalid_actions)
         return gumbel_muzero_policy(params=(role_fn_args, opponent_fn_args), rng_key=subkey, root=root,
                                     recurrent_fn=recurrent_fn, num_simulations=num_evaluations,
                                     invalid_actions=invalid_actions, max_depth=max_depth,

@@ -320,7 +320,8 @@ int hk_search_expand_scatter(const void* obs, const void* feat, const int32_t* n
 int hk_search_expand_gather_agent(const void* embeddings, const int32_t* parent, void* points_out, void* coords_out,
                                   int batch, int num_nodes, int max_points, int dim, void* stream);
 /* class = argmax_c host_logits[b, c] (first maximum, NaN beats every number; num_classes <= 2^dim - dim - 1),
- * mask = its subset; embeddings[b, node[b]] = points[b] ++ mask; features[b, node[b]] = feat[b];
+ * mask = its subset; embeddings[b, node[b]] = points[b] ++ mask; features[b, node[b]] = feat[b] (features may be
+ * NULL: nothing in an agent-role expansion reads a node's features again -- the agent network's input is agent_feat_out);
  * agent_feat_out [B, E + dim] = feat[b] ++ mask; class_out [B] (or NULL) = class                              */
 int hk_search_expand_scatter_agent(const void* points, const void* feat, const void* host_logits,
                                    const int32_t* node, void* embeddings, void* features, void* agent_feat_out,

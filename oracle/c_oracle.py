@@ -37,7 +37,7 @@ def lib() -> C.CDLL:
         protos = {}
         for name, (res, args) in A.PROTOTYPES.items():
             if name in ("hk_abi_version", "hk_strerror", "hk_has_fast_path", "hk_rollout_workspace_bytes",
-                        "hk_rollout_reduce_counts", "hk_rollout_values", "hk_step_features") or name.startswith("hk_search_"):
+                        "hk_rollout_reduce_counts", "hk_rollout_values") or name.startswith("hk_search_"):
                 continue  # launch plumbing / restated in oracle/search_oracle.py and np_oracle.rollout_postprocess
             args = list(args[:-1])  # no stream on the CPU
             protos["hko_" + name[3:]] = (res, args)
@@ -81,10 +81,14 @@ def flags_of(sem: str = "jax", noop_if_invalid=False, ignore_ended=False, compac
 
 def step(points: np.ndarray, coords=None, axis=None, *, stages: int, flags: int = 0,
          padding_value: float = -1.0, coords_kind: Optional[int] = None, reward_sign: float = 1.0,
-         max_points: Optional[int] = None, dim: Optional[int] = None):
+         max_points: Optional[int] = None, dim: Optional[int] = None, axis_logits: bool = False,
+         features: Optional[bool] = None):
     """Run hko_step.  `points` is [B, m, d] (or a [B, stride] record matrix when max_points/dim
     are given, e.g. an agent observation with the mask in its tail).
-    Returns dict(points, done, prev_done, reward, num_points)."""
+    axis_logits: `axis` is [B, d] float32 logits of the agent (HK_AXIS_MASKED_LOGITS: its move is the argmax over the
+    host's subset).  features: None, or scale_observation -- hko_step_features, the result's observation features
+    as `features` [B, m*d].
+    Returns dict(points, done, prev_done, reward, num_points[, features])."""
     points = np.ascontiguousarray(points)
     if points.ndim == 3:
         b, m, d = points.shape
@@ -117,15 +121,21 @@ def step(points: np.ndarray, coords=None, axis=None, *, stages: int, flags: int 
         axis = np.ascontiguousarray(axis)
         keep.append(axis)
         s.axis = _ptr(axis)
-        s.axis_dtype = _hk_dtype(axis)
+        s.axis_dtype = A.HK_AXIS_MASKED_LOGITS if axis_logits else _hk_dtype(axis)
     s.done_out, s.prev_done_out = _ptr(done), _ptr(prev)
     s.reward_out, s.num_points_out = _ptr(rew), _ptr(npts)
     s.padding_value, s.reward_sign = padding_value, reward_sign
     s.batch, s.max_points, s.dim, s.dtype = b, m, d, _hk_dtype(points)
     s.stages, s.flags = stages, flags
-    _check(lib().hko_step(C.byref(s)))
-    return dict(points=out, done=done.astype(bool), prev_done=prev.astype(bool), reward=rew,
-                num_points=npts)
+    res = dict(points=out, done=done.astype(bool), prev_done=prev.astype(bool), reward=rew, num_points=npts)
+    if features is None:
+        _check(lib().hko_step(C.byref(s)))
+    else:
+        feat = np.empty((b, m * d), dtype=points.dtype)
+        _check(lib().hko_step_features(C.byref(s), _ptr(feat), int(bool(features))))
+        res["features"] = feat
+    res["done"], res["prev_done"] = done.astype(bool), prev.astype(bool)
+    return res
 
 
 def shift(points, coords, axis, padding_value=-1.0, **kw):

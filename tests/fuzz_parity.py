@@ -79,7 +79,7 @@ def one_case(rng):
     sem = ["jax", "torch", "list"][rng.integers(0, 3)]
     pad = float(rng.choice([-1.0, -1.0, -1.0, -1e-8, -2.5]))
     force = int(rng.choice([0, 0, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_TWO_LANES, A.HK_FLAG_FORCE_FOUR_LANES,
-                           A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC]))
+                           A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC, A.HK_FLAG_FORCE_POOL]))
     noop, ign = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     if rng.integers(0, 4) == 0:  # the flag sets of the compiled rollout configurations
         noop = ign = (sem == "torch")
@@ -109,6 +109,25 @@ def one_case(rng):
     for k in ("points", "done", "prev_done", "reward", "num_points"):
         if not np.array_equal(got[k].cpu().numpy(), want[k]):
             raise Mismatch(f"STEP MISMATCH {k} {cfg}")
+    # hk_step_features / HK_AXIS_MASKED_LOGITS (the search's expansion) where the four-lane step kernel serves them
+    if (m, d) in ((20, 3), (10, 3), (20, 4)) and sem != "list" and not compact and (stages & 1) and \
+            force in (0, A.HK_FLAG_FORCE_FOUR_LANES):
+        scale = bool(rng.integers(0, 2))
+        lg = rng.standard_normal((b, d)).astype(np.float32)
+        lg[rng.random((b, d)) < 0.1] = np.nan
+        lg[rng.random((b, d)) < 0.2] = 0.5
+        cls32 = cls.astype(np.int32)
+        for axis, is_logits in ((ax, False), (lg, True)):
+            wantf = CO.step(p, cls32, axis, stages=stages, flags=flags_o, padding_value=pad, axis_logits=is_logits,
+                            features=scale)
+            feat = torch.empty((b, m * d), dtype=torch.float32, device="cuda")
+            gotf = ops.step(P, torch.as_tensor(cls32).cuda(), torch.as_tensor(axis).cuda(), stages=stages,
+                            flags=flags_p, padding_value=pad, want=("done", "reward"), features_out=feat,
+                            scale_observation=scale)
+            if not (np.array_equal(gotf["points"].cpu().numpy(), wantf["points"], equal_nan=True)
+                    and np.array_equal(feat.cpu().numpy(), wantf["features"], equal_nan=True)
+                    and np.array_equal(gotf["reward"].cpu().numpy(), wantf["reward"])):
+                raise Mismatch(f"STEP FEATURES MISMATCH {dict(cfg, logits=is_logits, scale=scale)}")
     # fused rollout with records (JAX semantics flags only make sense with fixed policies too)
     T = int(rng.integers(1, 25))
     hp = int(rng.choice([A.HK_HOST_RANDOM, A.HK_HOST_RANDOM, A.HK_HOST_ALL_COORD, A.HK_HOST_ZEILLINGER]))

@@ -123,3 +123,12 @@ def test_ops_refuse_cpu_tensors():
         ops.get_newton_polytope(torch.zeros(2, 4, 3))
     with pytest.raises(TypeError):
         ops.get_dones(torch.zeros(2, 4, 3))
+
+
+def test_graft_entry_build_runs():
+    """__graft_entry__.build() -- the driver's "does it build" check -- compiles (make: up to date here), loads the
+    library, checks its ABI version against the python binding and builds the oracle"""
+    import __graft_entry__ as G
+    G.build()
+    from hironaka_amd import _abi, _lib
+    assert _lib.lib().hk_abi_version() == _abi.HK_ABI_VERSION

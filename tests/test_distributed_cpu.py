@@ -44,10 +44,20 @@ def _worker(rank, world, port, total, tmpdir):
             pass
         obs = D.all_gather_rollout((torch.from_numpy(rec["obs"][0]), torch.from_numpy(rec["axis"][0]),
                                     torch.from_numpy(rec["reward"][0])), shard)
+        # simulate()'s tensors are flattened to [B * T, ...] rows: T rows per game, gathered in game order
+        flat = torch.from_numpy(np.ascontiguousarray(rec["obs"].transpose(1, 0, 2, 3)).reshape(shard.size * T, m * d))
+        rows = D.all_gather_rollout((flat, flat[:, :1].clone()), shard, rows_per_game=T)
+        assert rows[0].shape[0] == total * T and rows[1].shape == (total * T, 1)
+        assert torch.equal(D.all_gather_games(flat, shard, direct=True, rows_per_game=T), rows[0])
+        try:  # every rank raises together (a rank raising alone would leave the others inside the collective)
+            D.all_gather_games(flat[: flat.shape[0] - (1 if rank == 0 else 0)], shard, rows_per_game=T)
+            raise AssertionError("an inconsistent local batch on ONE rank must raise on every rank")
+        except ValueError:
+            pass
         counts = D.all_reduce_counts(torch.from_numpy(rec["done_count"].astype(np.int64)))
         if rank == 0:
             np.savez(os.path.join(tmpdir, "out.npz"), final=gathered.numpy(), obs=obs[0].numpy(), axis=obs[1].numpy(),
-                     reward=obs[2].numpy(), counts=counts.numpy())
+                     reward=obs[2].numpy(), counts=counts.numpy(), rows=rows[0].numpy())
     finally:
         dist.destroy_process_group()
 
@@ -63,6 +73,7 @@ def test_two_rank_shards_equal_unsharded(tmp_path, total, world):
     assert np.array_equal(got["obs"], rec["obs"][0]) and np.array_equal(got["axis"], rec["axis"][0])
     assert np.array_equal(got["reward"], rec["reward"][0])
     assert np.array_equal(got["counts"], rec["done_count"].astype(np.int64))
+    assert np.array_equal(got["rows"], np.ascontiguousarray(rec["obs"].transpose(1, 0, 2, 3)).reshape(total * 6, 30))
 
 
 def test_shard_range_partitions():

@@ -761,7 +761,7 @@ def test_deferred_counts_equal_per_launch_counts(spec):
     assert torch.equal(got, want) and int(ws.sum()) == 0
 
 
-@pytest.mark.parametrize("spec", [(20, 3), (10, 3), (8, 4), (4, 3), (50, 4), (33, 4), (64, 3), (12, 6), (7, 3), (9, 7)])
+@pytest.mark.parametrize("spec", [(20, 3), (20, 4), (10, 3), (8, 4), (4, 3), (50, 4), (33, 4), (64, 3), (12, 6), (7, 3), (9, 7)])
 def test_features_match_oracle(spec):
     """hk_get_features (jax/util.py:186-197: rescale + rows in descending order, last coordinate primary) on the
     register-resident, team and generic kernels: game states, duplicate rows, ties on the primary coordinate,
@@ -790,6 +790,23 @@ def test_features_match_oracle(spec):
     # big batch, ragged tail
     big = host(ops.generate_points(5003, m, d, 20, seed=3))
     assert np.array_equal(host(ops.get_features(dev(big), True)), CO.get_features(big, True))
+    # fractional coordinates (dyadic fractions: exact sums, many equal keys after the rescale) -- the class of input
+    # behind the round-2 development mismatch at (20,4), b = 63 (tests/golden/fuzz_regression_features_20_4.npz)
+    for bb in (63, 300):
+        f = (rng.integers(0, 33, (bb, m, d)) / 8.0).astype(np.float32)
+        f[rng.random((bb, m)) < 0.4] = -1.0
+        for scale in (True, False):
+            assert np.array_equal(host(ops.get_features(dev(f), scale)), CO.get_features(f, scale)), (spec, bb, scale)
+
+
+def test_features_fuzz_regression_20_4():
+    """the configuration of the round-2 development mismatch (fuzz_parity: m=20, d=4, b=63, dyadic fractions,
+    scale=True) as a committed fixture: inputs + the oracle's features"""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "fuzz_regression_features_20_4.npz"))
+    for scale, key in ((True, "features_scaled"), (False, "features_unscaled")):
+        assert np.array_equal(CO.get_features(fx["points"], scale), fx[key])  # (the fixture pins the oracle too)
+        assert np.array_equal(host(ops.get_features(dev(fx["points"]), scale)), fx[key])
 
 
 @pytest.mark.parametrize("spec", [(20, 3), (10, 3), (8, 4), (20, 4), (4, 3), (7, 3), (50, 4), (64, 6), (9, 7)])
@@ -876,6 +893,54 @@ def test_step_with_agent_logits_equals_masked_argmax_then_step():
         ops.step(P, torch.zeros(8, dtype=torch.int32, device="cuda"), torch.zeros((8, 3), device="cuda"),
                  stages=A.HK_STAGE_SHIFT | A.HK_STAGE_NEWTON)
     assert err.value.status == A.HK_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("spec", [(20, 3), (10, 3), (20, 4)])
+def test_step_features_and_agent_logits_match_oracle(spec):
+    """hk_step_features and HK_AXIS_MASKED_LOGITS DIRECTLY against the oracle (hko_step_features = hko_step +
+    hko_get_features; the masked argmax of jax/util.py:287-327 inside hko_step): generated and dense states, NaN / tied
+    logits, with and without rescaling, JAX and torch semantics -- and non-canonical (finite) games (a negative
+    coordinate in a live row, a partly padded row, an irregular padding row) in some waves only: those waves take the
+    exact generic path, which must produce the features too"""
+    m, d = spec
+    rng = np.random.default_rng(31 * m + d)
+    for b in (1, 17, 1000, 4099):
+        for stages, sem in ((7, "jax"), (5, "jax"), (7, "torch"), (15, "jax")):
+            for kind in ("generated", "dense", "poisoned"):
+                p = host(ops.generate_points(b, m, d, 20, seed=b + m, newton=kind != "dense", reposition=kind != "dense"))
+                if kind == "poisoned":
+                    for g in range(0, b, 37):       # one game in (roughly) every other wave of 16
+                        if g % 3 == 0:
+                            p[g, 0, 0] = -0.5       # a negative coordinate in a live row
+                        elif g % 3 == 1:
+                            p[g, 0] = 2.0
+                            p[g, 0, d - 1] = -1.0   # a partly padded row
+                        else:
+                            p[g, m - 1] = -3.0      # an irregular padding row
+                cls = rng.integers(0, 2 ** d - d - 1, b).astype(np.int32)
+                ax = rng.integers(0, d, b).astype(np.int32)
+                lg = rng.standard_normal((b, d)).astype(np.float32)
+                lg[rng.random((b, d)) < 0.1] = np.nan
+                lg[rng.random((b, d)) < 0.15] = 0.25
+                fo = CO.flags_of(sem=sem, noop_if_invalid=sem != "jax", ignore_ended=sem == "torch")
+                fp = ops.make_flags(sem, sem != "jax", sem == "torch")
+                for axis, is_logits in ((ax, False), (lg, True)):
+                    for scale in (True, False):
+                        want = CO.step(p, cls, axis, stages=stages, flags=fo, axis_logits=is_logits, features=scale)
+                        feat = torch.empty((b, m * d), dtype=torch.float32, device="cuda")
+                        got = ops.step(dev(p), dev(cls), dev(axis), stages=stages, flags=fp,
+                                       want=("done", "prev_done", "reward", "num_points"), features_out=feat,
+                                       scale_observation=scale)
+                        tag = (spec, b, stages, sem, kind, is_logits, scale)
+                        assert np.array_equal(host(got["points"]), want["points"], equal_nan=True), tag
+                        assert np.array_equal(host(feat), want["features"], equal_nan=True), tag
+                        for k in ("done", "prev_done", "reward", "num_points"):
+                            assert np.array_equal(host(got[k]), want[k]), (k, tag)
+                    if is_logits:  # the plain step with the agent's logits as its axis
+                        want = CO.step(p, cls, axis, stages=stages, flags=fo, axis_logits=True)
+                        got = ops.step(dev(p), dev(cls), dev(axis), stages=stages, flags=fp, want=("done", "reward"))
+                        assert np.array_equal(host(got["points"]), want["points"], equal_nan=True), (spec, b, stages, sem, kind)
+                        assert np.array_equal(host(got["reward"]), want["reward"])
 
 
 def test_step_features_equals_step_then_get_features():

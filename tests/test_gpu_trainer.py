@@ -1,5 +1,5 @@
 """HipTrainer (hironaka_amd/trainer_api.py): the reference's `JAXTrainer.simulate(key, role, use_mcts_policy,
-use_unified_tree)` / `compute_rho` / `validate` entry points over the HIP environment.  Shapes and sanity checks
+use_unified_tree)` / `compute_rho` entry points over the HIP environment.  Shapes and sanity checks
 follow test/testJAXTrainer.py:36-66; BASELINE configs[4] (8192 games x 32 simulations x 20 moves) runs at size."""
 import numpy as np
 import pytest
@@ -105,16 +105,34 @@ def test_simulate_baseline_config5_at_size():
     assert bool((v[finished] > 0).all())
 
 
-def test_compute_rho_and_validate():
+def test_compute_rho_named_and_network_players():
+    import functools
+    from hironaka_amd.functional import action_wrapper
+    from hironaka_amd.players import choose_first_agent_fn
     t = make_trainer()
     rho, details = t.compute_rho("random", "random", batch_size=512, num_of_loops=2, max_length=12, key=9)
     assert len(details) == 12 and sum(details) <= 1024 and 0 < rho < 1
     # a network host against a fixed agent: the reference-shaped step loop
-    hosts, agents = t.get_cached_hosts_agents_for_validation(256)
-    rho2, det2 = t.compute_rho(hosts[0], agents[2], batch_size=256, num_of_loops=1, max_length=8, key=3)
+    host = action_wrapper(functools.partial(t.policy_fns["host"], params=t.host_params), None)
+    agent = functools.partial(choose_first_agent_fn, spec=t.spec)
+    rho2, det2 = t.compute_rho(host, agent, batch_size=256, num_of_loops=1, max_length=8, key=3)
     assert len(det2) == 8 and sum(det2) <= 256
-    rhos, dets = t.validate(batch_size=128, num_of_loops=1, max_length=8, key=1)
-    assert len(rhos) == 7 and all(len(x) == 8 for x in dets)
+
+
+def test_parameter_objects_do_not_accumulate_captures():
+    """a trainer that hands over NEW parameter objects every optimiser step (the functional style of the reference)
+    keeps one argument tuple and one captured search per role and kind of tree; in-place updates keep the capture"""
+    t = make_trainer(use_graph=True)
+    t.simulate(1, "host")
+    loop_captures = lambda: sum(len(c.cell_contents) for f in t._sim_fns.values() for c in (f.__closure__ or ())
+                                if isinstance(getattr(c, "cell_contents", None), dict))
+    first_args = t._fn_args[("host", False)]
+    t.simulate(2, "host")
+    assert t._fn_args[("host", False)] is first_args  # same objects: same tuples, same capture
+    for step in range(3):
+        t.host_params = tuple(p.clone() for p in t.host_params)
+        t.simulate(3 + step, "host")
+    assert len(t._fn_args) == 1 and t._fn_args[("host", False)][0] is t.host_params
 
 
 def test_expand_operators_against_oracle():
