@@ -130,7 +130,8 @@ __device__ __forceinline__ void quad_slab_load(const float* base, float* image, 
 
 __device__ __forceinline__ void wait_vmem_all() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0)
 
-template <int M, int D>
+// NT: non-temporal stores (write-once streams: the per-step observations of a recording rollout)
+template <int M, int D, bool NT = false>
 __device__ __forceinline__ void quad_slab_store(const float* image, float* base, int ngames, int lane) {
   using G = QuadGeom<M, D>;
   using V = typename VecOf<G::W>::type;
@@ -154,14 +155,19 @@ __device__ __forceinline__ void quad_slab_store(const float* image, float* base,
 #pragma unroll
       for (int u = 0; u < B; ++u) {
         const int it = i0 + u;
-        if (it < G::QL && ((it + 1) * kWave <= FULL || lane < FULL - it * kWave))
-          *reinterpret_cast<V*>(dst + it * kWave * G::W) = v[u];
+        if (it < G::QL && ((it + 1) * kWave <= FULL || lane < FULL - it * kWave)) {
+          if constexpr (NT) __builtin_nontemporal_store(v[u], reinterpret_cast<V*>(dst + it * kWave * G::W));
+          else *reinterpret_cast<V*>(dst + it * kWave * G::W) = v[u];
+        }
       }
     } else {
 #pragma unroll
       for (int u = 0; u < B; ++u) {
         const int it = i0 + u;
-        if (it < G::QL && (unsigned)lane + it * kWave < total) *reinterpret_cast<V*>(dst + it * kWave * G::W) = v[u];
+        if (it < G::QL && (unsigned)lane + it * kWave < total) {
+          if constexpr (NT) __builtin_nontemporal_store(v[u], reinterpret_cast<V*>(dst + it * kWave * G::W));
+          else *reinterpret_cast<V*>(dst + it * kWave * G::W) = v[u];
+        }
       }
     }
   }

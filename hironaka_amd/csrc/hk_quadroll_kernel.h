@@ -23,8 +23,8 @@
 //   * fixed-point exit as in the other rollout kernels (every game of the wave without a point, or with one point at the
 //     origin);
 //   * at the end the image is rebuilt (padding everywhere, survivors at their own rows) and stored as one slab.
-// Plain rollouts only (no per-step records, no Zeillinger host -- its choice depends on the state --, no sorted output);
-// exactness guard and whole-wave fallback on the generic routines as in the other kernels.
+// Plain and recording rollouts (REC: per-step observations / records); no Zeillinger host -- its choice depends on the
+// state --, no sorted output; exactness guard and whole-wave fallback on the generic routines as in the other kernels.
 #pragma once
 
 #include "hk_quad_kernel.h"
@@ -201,7 +201,44 @@ __device__ __forceinline__ void qr_redeal(float (&q)[R * D], int (&orig)[R], flo
   wave_lds_fence();  // (the compact image is scratch again: qd_newton_lds parks rows there)
 }
 
-template <int M, int D, int HOT, int WPB>
+// the wave's image from the rows in registers: padding everywhere (16-B pieces), then every live row at its own place
+template <int M, int D, int R>
+__device__ __forceinline__ void qr_build_image(const float (&q)[R * D], const int (&orig)[R], float* region, float* mine,
+                                               int smax, float pad, int lane) {
+  using G = QuadGeom<M, D>;
+  wave_lds_fence();
+#pragma unroll
+  for (int it = 0; it < G::QL; ++it) {
+    const int qq = lane + it * kWave;
+    if (qq < kQuadGames * G::Q) {
+      if constexpr (G::W == 4) *reinterpret_cast<vf4*>(region + qq * 4) = vf4{pad, pad, pad, pad};
+      else if constexpr (G::W == 2) *reinterpret_cast<vf2*>(region + qq * 2) = vf2{pad, pad};
+      else region[qq] = pad;
+    }
+  }
+  wave_lds_fence();
+  unrolled_while<0, R>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (s >= smax) return false;
+    if (q[s * D] < INFINITY) {
+      float* dst = mine + orig[s] * D;
+      if constexpr (D == 4) {
+        *reinterpret_cast<vf4*>(dst) = vf4{q[s * D], q[s * D + 1], q[s * D + 2], q[s * D + 3]};
+      } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) dst[k] = q[s * D + k];
+      }
+    }
+    return true;
+  });
+  wave_lds_fence();
+}
+
+// REC: the recording rollout -- per step the observation (the state before the step, rebuilt from the rows in
+// registers and stored as one slab) and / or the small records (host class, axis, done, reward) -- what the
+// simulate-shaped consumers read (hironaka/jax/simulation_fn.py:196-211).  Once every game of the wave is at its
+// fixed point only the stores go on (the same image, the policies' draws, done = 1, reward = 0).
+template <int M, int D, int HOT, int WPB, bool REC = false>
 __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) void quadroll_kernel(
     const float* in0, int64_t in_stride0, int batch0, const Params prm) {
   using G = QuadGeom<M, D>;
@@ -311,7 +348,15 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
     for (int t = 0; t < nsteps; ++t) {
       int axis = -1, cls = 0;
       uint32_t mask;
+      if constexpr (REC) {
+        if (prm.obs_out) {  // the state before the step
+          wave_lds_fence();
+          quad_slab_store<M, D>(region, (float*)prm.obs_out + ((int64_t)t * prm.batch + g0) * G::N, ngames, lane);
+          wave_lds_fence();
+        }
+      }
       fast_policy<D>(seed, host_policy, agent_policy, gg, step0 + (uint32_t)t, pcache, cls, axis, mask, 0);
+      const bool prev_done = np < 2;
       if (leader) {
         for (int k = 0; k < prm.d; ++k) cs[k] = (float)((mask >> k) & 1u);
         stages_game<float>(mine, prm.m, prm.d, cs, axis, pad, stages, flags);
@@ -319,6 +364,15 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
       }
       const bool done = np < 2;
       if (done && length < 0) length = t + 1;
+      if constexpr (REC) {
+        if (leader) {
+          const int64_t at = (int64_t)t * prm.batch + g;
+          if (prm.r_host_class_out) prm.r_host_class_out[at] = cls;
+          if (prm.r_axis_out) prm.r_axis_out[at] = axis;
+          if (prm.r_done_out) prm.r_done_out[at] = done;
+          if (prm.r_reward_out) prm.r_reward_out[at] = prm.reward_sign * (float)(done && !prev_done);
+        }
+      }
       if (prm.count_ws) {
         const unsigned long long bd = __ballot(leader && done);
         if (lane == 0 && bd)
@@ -394,6 +448,30 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   int length = (np < 2) ? 0 : -1;
 
   // ---- the steps: a staircase of loops, one per bucket of slots per lane ---------------------------------------------
+  const bool want_obs = REC && prm.obs_out != nullptr;
+  const bool want_records = REC && (prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out);
+  // one step's records of the lane's game (leader lanes): `a` = the action byte, done / prev_done around the step.
+  // Addresses: a scalar row base (step * batch + the wave's first game) + the lane's game index as a 32-bit offset --
+  // no 64-bit address arithmetic per lane and store; the four pointers and the batch live in SGPRs.
+  int32_t* rec_cls = REC ? prm.r_host_class_out : nullptr;
+  int32_t* rec_axis = REC ? prm.r_axis_out : nullptr;
+  uint8_t* rec_done = REC ? prm.r_done_out : nullptr;
+  float* rec_reward = REC ? prm.r_reward_out : nullptr;
+  float* rec_obs = REC ? (float*)prm.obs_out : nullptr;
+  int64_t rec_batch = prm.batch;
+  float rec_sign = prm.reward_sign;
+  if constexpr (REC) asm volatile("" : "+s"(rec_cls), "+s"(rec_axis), "+s"(rec_done), "+s"(rec_reward), "+s"(rec_obs),
+                                  "+s"(rec_batch), "+s"(rec_sign));
+  auto put_records = [&](int tt, uint32_t a, bool done, bool prev_done) {
+    if (want_records && leader) {
+      const int64_t row = (int64_t)tt * rec_batch + g0;  // (scalar)
+      const unsigned ug = (unsigned)gi;
+      if (rec_cls) (rec_cls + row)[ug] = encode_mask(a & 31u);
+      if (rec_axis) (rec_axis + row)[ug] = (int32_t)(a >> 5);
+      if (rec_done) (rec_done + row)[ug] = done;
+      if (rec_reward) (rec_reward + row)[ug] = rec_sign * (float)(done && !prev_done);
+    }
+  };
   int t = 0;
   bool stop = false;
   while (t < nsteps && !stop) {  // one pass per window of actions (episodes of up to 24 steps: one pass)
@@ -417,10 +495,19 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
         const uint32_t a = arow[(int)(step0 + (uint32_t)t - wstep0) * kQuadGames];
         const uint32_t cmask = a & 31u;
         const int axis = (int)(a >> 5);
+        if constexpr (REC) {
+          if (want_obs) {  // the state before the step
+            qr_build_image<M, D, R>(q, orig, region, mine, smax, pad, lane);
+            quad_slab_store<M, D, true>(region, rec_obs + ((int64_t)t * rec_batch + g0) * G::N, ngames, lane);
+            wave_lds_fence();
+          }
+        }
+        const bool prev_done = np < 2;
         np = qr_stages<M, CW, R, D, NB>(q, cmask, axis, np, j, flags, stages, cmine, smax);
         if (!active) np = 2;
         const bool done = np < 2;
         if (done && length < 0) length = t + 1;
+        if constexpr (REC) put_records(t, a, done, prev_done);
         if constexpr (NB == 1) {
           // Fixed point (hk_duo_kernel.h): once every game of the wave is down to one point at the origin (or none)
           // nothing changes any more
@@ -448,32 +535,25 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   if (leader && prm.game_length_out) prm.game_length_out[g] = length;
 
   // ---- publish: padding everywhere, the survivors at their own rows ---------------------------------------------------
-  wave_lds_fence();
-#pragma unroll
-  for (int it = 0; it < G::QL; ++it) {
-    const int qq = lane + it * kWave;
-    if (qq < kQuadGames * G::Q) {
-      if constexpr (G::W == 4) *reinterpret_cast<vf4*>(region + qq * 4) = vf4{pad, pad, pad, pad};
-      else if constexpr (G::W == 2) *reinterpret_cast<vf2*>(region + qq * 2) = vf2{pad, pad};
-      else region[qq] = pad;
+  qr_build_image<M, D, R>(q, orig, region, mine, smax, pad, lane);
+  if constexpr (REC) {
+    // every game of the wave at its fixed point before the last step: the state does not change any more, the records
+    // go on (the same image as observation, the policies' draws, done, no reward)
+    for (; t < nsteps; ++t) {
+      if ((uint32_t)((step0 + (uint32_t)t) >> 1) - wb0 >= (uint32_t)kQrBlocks) {
+        wave_lds_fence();
+        wb0 = (step0 + (uint32_t)t) >> 1;
+        const uint32_t nb = wb_last - wb0 + 1u;
+        qr_policy_fill<D>(act, gg0, wb0, (int)(nb < (uint32_t)kQrBlocks ? nb : (uint32_t)kQrBlocks), seed, host_policy,
+                          agent_policy, lane);
+        wave_lds_fence();
+      }
+      if (want_obs)
+        quad_slab_store<M, D, true>(region, rec_obs + ((int64_t)t * rec_batch + g0) * G::N, ngames, lane);
+      const uint32_t a = act[(int)(step0 + (uint32_t)t - (wb0 << 1)) * kQuadGames + gi];
+      put_records(t, a, np < 2, np < 2);
     }
   }
-  wave_lds_fence();
-  unrolled_while<0, R>([&](auto sc) {
-    constexpr int s = decltype(sc)::value;
-    if (s >= smax) return false;
-    if (q[s * D] < INFINITY) {
-      float* dst = mine + orig[s] * D;
-      if constexpr (D == 4) {
-        *reinterpret_cast<vf4*>(dst) = vf4{q[s * D], q[s * D + 1], q[s * D + 2], q[s * D + 3]};
-      } else {
-#pragma unroll
-        for (int k = 0; k < D; ++k) dst[k] = q[s * D + k];
-      }
-    }
-    return true;
-  });
-  wave_lds_fence();
   quad_slab_store<M, D>(region, (float*)prm.out + g0 * G::N, ngames, lane);
   // the finished-game counts: games whose first finished step is <= s, for every s (a finished game stays finished)
   if (prm.count_ws) {
@@ -488,11 +568,10 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
-// plain rollouts (no per-step records, no Zeillinger host, no sorted output) of float32, contiguous, W-aligned records
+// rollouts (no Zeillinger host, no sorted output) of float32, contiguous, W-aligned records
 inline bool quadroll_request_ok(const Params& prm) {
   if (prm.mode != kModeRollout || prm.m > 255) return false;
   if (prm.host_policy == HK_HOST_ZEILLINGER) return false;
-  if (prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out) return false;
   if ((prm.stages & HK_STAGE_NEWTON) &&
       ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)))
     return false;
@@ -511,6 +590,16 @@ int launch_quadroll_t(Params prm, hipStream_t stream) {
   prm.pad_f32 = (float)prm.pad;
   launch_prepare();
   const int hot = fast_hot_config(prm);
+  if (prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out) {
+    if (prm.obs_out && reinterpret_cast<uintptr_t>(prm.obs_out) % (QuadGeom<M, D>::W * 4)) return HK_ERR_ALIGN;
+    if (hot == kHotJax)
+      hipLaunchKernelGGL((quadroll_kernel<M, D, kHotJax, WPB, true>), dim3(grid), dim3(kWave * WPB), 0, stream,
+                         (const float*)prm.in, prm.in_stride, prm.batch, prm);
+    else
+      hipLaunchKernelGGL((quadroll_kernel<M, D, kHotNone, WPB, true>), dim3(grid), dim3(kWave * WPB), 0, stream,
+                         (const float*)prm.in, prm.in_stride, prm.batch, prm);
+    return launch_status();
+  }
   if (hot == kHotJax)
     hipLaunchKernelGGL((quadroll_kernel<M, D, kHotJax, WPB>), dim3(grid), dim3(kWave * WPB), 0, stream,
                        (const float*)prm.in, prm.in_stride, prm.batch, prm);
@@ -535,8 +624,12 @@ inline bool quadroll_supported(const Params& prm, int dtype) {
 // ... and, on the small shapes, batches of up to two of its waves per SIMD (32 768 games on an MI355X): measured
 // (scripts/probe_pool.py, (20,3)): 14.0 / 15.0 / 17.4 us per 20-step episode at 4 096 / 16 384 / 32 768 games against
 // 16.9 / 18.3 / 18.8 on two lanes per game, 24.5 against 22.2 at 65 536
+// Recording rollouts: at every size (scripts/probe_records.py, (20,3), per 20-step episode incl. the counter reduce:
+// 39.8 against 48.6 us with the small records and 69.5 against 82.1 us with the observations at 65 536 games, 90.6 / 240
+// against 114 / 279 us at 262 144).
 inline bool quadroll_default(const Params& prm, int simds) {
   if (prm.m > 32) return true;
+  if (prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out) return true;
   return ((int64_t)prm.batch + kQuadGames - 1) / kQuadGames <= (int64_t)2 * simds;
 }
 

@@ -402,18 +402,22 @@ def test_generate_matches_oracle(spec, force_generic):
                                                 ((6, 5), True), ((50, 4), False), ((7, 3), False), ((6, 5), False)])
 def test_rollout_matches_oracle(spec, force_generic):
     m, d = spec
-    fl = A.HK_FLAG_FORCE_GENERIC if force_generic else 0
     p0 = CO.generate_points(333, m, d, 20, 5)
+    # (the recording rollouts of every family that serves the shape: default, four lanes, two lanes / team)
+    families = (A.HK_FLAG_FORCE_GENERIC,) if force_generic else (0, A.HK_FLAG_FORCE_FOUR_LANES, A.HK_FLAG_FORCE_TWO_LANES,
+                                                                  A.HK_FLAG_FORCE_TEAM)
     for hp in (A.HK_HOST_RANDOM, A.HK_HOST_ALL_COORD, A.HK_HOST_ZEILLINGER):
         for ap in (A.HK_AGENT_RANDOM, A.HK_AGENT_RANDOM_LEGAL, A.HK_AGENT_CHOOSE_FIRST, A.HK_AGENT_CHOOSE_LAST):
-            want_p, want = CO.rollout(p0, 9, 99, game_offset=17, step_offset=3, host_policy=hp, agent_policy=ap)
-            P = dev(p0.copy())
-            got = ops.rollout(P, 9, 99, game_offset=17, step_offset=3, host_policy=hp, agent_policy=ap, flags=fl,
-                              record=("obs", "host_class", "axis", "done", "reward", "game_length"))
-            assert np.array_equal(host(P), want_p), (hp, ap)
-            for k in ("obs", "host_class", "axis", "done", "reward", "game_length"):
-                assert np.array_equal(host(got[k]), want[k]), (k, hp, ap)
-            assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"])
+            for T, so in ((9, 3), (27, 0)):
+                want_p, want = CO.rollout(p0, T, 99, game_offset=17, step_offset=so, host_policy=hp, agent_policy=ap)
+                for fl in families:
+                    P = dev(p0.copy())
+                    got = ops.rollout(P, T, 99, game_offset=17, step_offset=so, host_policy=hp, agent_policy=ap, flags=fl,
+                                      record=("obs", "host_class", "axis", "done", "reward", "game_length"))
+                    assert np.array_equal(host(P), want_p), (hp, ap, T, fl)
+                    for k in ("obs", "host_class", "axis", "done", "reward", "game_length"):
+                        assert np.array_equal(host(got[k]), want[k]), (k, hp, ap, T, fl)
+                    assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"])
 
 
 @pytest.mark.parametrize("spec", [(20, 3), (10, 3), (4, 3), (8, 4), (20, 4), (50, 4)])
