@@ -406,6 +406,129 @@ __device__ __forceinline__ void qd_newton_lds(float (&q)[R * D], float* cmine, i
   wave_lds_fence();  // the compact image is written again after the stages
 }
 
+// The same for many slots per lane in TWO LEVELS (round 3).  Domination is transitive and the result of the test is the set
+// of minimal rows (of equal rows the one with the lowest rank), so a row may be dropped as soon as ANY row dominates it --
+// whatever happens to that row later: its own dominator dominates both.  Level 1: every lane tests the triangle of its
+// OWN slots (no communication: NB (NB - 1) / 2 tests); a quarter of a game's rows, drawn across the game, already
+// removes most dominated rows (50 random rows in dimension 4: ~25 of them survive level 1, ~15 the whole test).  The
+// survivors are parked at their rank among the survivors (popcounts of the four lanes' masks: rank order = row order,
+// which decides between equal rows) with their slot's index next to them, re-dealt four ways, and level 2 is the
+// segmented loop above over the SURVIVORS only (in a bucket of 4, 6, 8, 10 or NB slots per lane: the widest game of
+// the wave decides); its verdicts return through a byte per row.  For 50 dense rows: 78 + ~75 pair tests per lane
+// instead of 306.  `tsc`: 2 x 64 bytes of scratch per game (slot indices, verdicts).
+template <int M, int CW, int R, int D, int NB>
+__device__ __forceinline__ void qd_newton_two_level(float (&q)[R * D], float* cmine, uint8_t* tsc, int j, int) {
+  static_assert(kQuad * NB <= 64 + kQuad, "a slot's index travels as a byte below 64");
+  float acc[NB];
+#pragma unroll
+  for (int s = 0; s < NB; ++s) acc[s] = INFINITY;
+#pragma unroll
+  for (int a = 0; a + 1 < NB; ++a) {
+#pragma unroll
+    for (int b = a + 1; b < NB; ++b) {
+      float t, u;
+      qd_extrema<D>(&q[a * D], &q[b * D], t, u);
+      acc[b] = hk_fmin(acc[b], t);
+      acc[a] = hk_fmin(acc[a], (t > 0.0f) ? -u : 1.0f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  uint32_t lm = 0;  // my slots that are live and survived level 1
+#pragma unroll
+  for (int s = 0; s < NB; ++s) lm |= (q[s * D] < INFINITY && acc[s] > 0.0f) ? (1u << s) : 0u;
+  const int np1 = q_sum(__popc(lm));
+  int s1 = NB;  // slots per lane at level 2: the wave-uniform maximum of ceil(np1 / 4)
+#pragma nounroll
+  while (s1 > 1 && !__any(np1 > kQuad * (s1 - 1))) --s1;
+  const uint32_t l1 = (uint32_t)qperm_i<kQuadUp1>((int)lm), l2 = (uint32_t)qperm_i<kQuadUp2>((int)lm),
+                 l3 = (uint32_t)qperm_i<kQuadUp3>((int)lm);
+  const bool b1 = ((j + 1) & 3) < j, b2 = ((j + 2) & 3) < j, b3 = ((j + 3) & 3) < j;
+  uint8_t* tags = tsc;
+  uint8_t* verdict = tsc + 64;
+#pragma unroll
+  for (int s = 0; s < NB; ++s) {
+    const uint32_t below = (1u << s) - 1u, at = 1u << s;
+    const int rank = __popc(lm & below) + __popc(l1 & (below | (b1 ? at : 0u))) + __popc(l2 & (below | (b2 ? at : 0u))) +
+                     __popc(l3 & (below | (b3 ? at : 0u)));
+    if ((lm >> s) & 1u) {
+      float* dst = cmine + rank * CW;
+      if constexpr (D == 4) {
+        *reinterpret_cast<vf4*>(dst) = vf4{q[s * D], q[s * D + 1], q[s * D + 2], q[s * D + 3]};
+      } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) dst[k] = q[s * D + k];
+      }
+      tags[rank] = (uint8_t)(kQuad * s + j);
+    }
+  }
+  wave_lds_fence();
+  auto level2 = [&](auto nbc) __attribute__((always_inline)) {
+    constexpr int NB2 = decltype(nbc)::value;
+    float q2[NB2 * D];
+    int tag2[NB2];
+#pragma unroll
+    for (int s = 0; s < NB2; ++s) {
+      const bool has = kQuad * s + j < np1;
+      const int r = has ? kQuad * s + j : 0;
+      const float* src = cmine + r * CW;
+      if constexpr (D == 4) {
+        const vf4 v = *reinterpret_cast<const vf4*>(src);
+        q2[s * D] = has ? v.x : INFINITY;
+        q2[s * D + 1] = has ? v.y : INFINITY;
+        q2[s * D + 2] = has ? v.z : INFINITY;
+        q2[s * D + 3] = has ? v.w : INFINITY;
+      } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const float v = src[k];
+          q2[s * D + k] = has ? v : INFINITY;
+        }
+      }
+      tag2[s] = has ? (int)tags[r] : -1;
+    }
+    // (the rolled loop over the parked survivors -- they lie at their ranks already --, not the unrolled DPP test:
+    // inside this body that one spilled 1.4 KB per lane at (50,4))
+    qd_newton_lds<M, CW, NB2, D, NB2>(q2, cmine, j, np1);
+#pragma unroll
+    for (int s = 0; s < NB2; ++s)
+      if (tag2[s] >= 0) verdict[tag2[s]] = (q2[s * D] < INFINITY) ? (uint8_t)0 : (uint8_t)1;
+  };
+  if (s1 <= 4) level2(std::integral_constant<int, (NB < 4 ? NB : 4)>{});
+  else if (s1 <= 6) level2(std::integral_constant<int, (NB < 6 ? NB : 6)>{});
+  else if (s1 <= 8) level2(std::integral_constant<int, (NB < 8 ? NB : 8)>{});
+  else if (s1 <= 10) level2(std::integral_constant<int, (NB < 10 ? NB : 10)>{});
+  else level2(std::integral_constant<int, NB>{});
+  wave_lds_fence();
+  // my slots back from where they are parked (the registers that held them were free during level 2: with them live
+  // across it the (50,4) kernel spilled 1.2 KB per lane)
+#pragma unroll
+  for (int s = 0; s < NB; ++s) {
+    const uint32_t below = (1u << s) - 1u, at = 1u << s;
+    const int rank = __popc(lm & below) + __popc(l1 & (below | (b1 ? at : 0u))) + __popc(l2 & (below | (b2 ? at : 0u))) +
+                     __popc(l3 & (below | (b3 ? at : 0u)));
+    const bool kept = ((lm >> s) & 1u) && verdict[(kQuad * s + j) & 63] == 0;
+    int off = (kept ? rank : 0) * CW;
+    // (opaque: otherwise the compiler forwards the values stored at this very address before level 2 and keeps the
+    // whole row array live across it)
+    asm volatile("" : "+v"(off));
+    const float* src = cmine + off;
+    if constexpr (D == 4) {
+      const vf4 v = *reinterpret_cast<const vf4*>(src);
+      q[s * D] = kept ? v.x : INFINITY;
+      q[s * D + 1] = kept ? v.y : INFINITY;
+      q[s * D + 2] = kept ? v.z : INFINITY;
+      q[s * D + 3] = kept ? v.w : INFINITY;
+    } else {
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const float v = src[k];
+        q[s * D + k] = kept ? v : INFINITY;
+      }
+    }
+  }
+  wave_lds_fence();  // the compact image is written again after the stages
+}
+
 // list semantics (_list_ops.py:25-41): position of each of the lane's rows among the game's live rows in descending
 // lexicographic order, coordinate 0 first (rows are distinct after the Newton stage): the rows of the other three
 // lanes arrive through DPP, every lane counts for its own rows
@@ -513,12 +636,16 @@ __device__ __forceinline__ void qd_ranks_stable(const float (&q)[R * D], int j, 
 template <int M, int CW, int R, int D, int NB>
 __device__ __forceinline__ int qd_stages(float (&q)[R * D], const float (&c)[D], int axis, int np, int j,
                                          unsigned flags, unsigned stages, float* cmine, int slots_end, bool sorted,
-                                         int (&rank)[R]) {
+                                         int (&rank)[R], uint8_t* tsc = nullptr) {
   if (stages & HK_STAGE_SHIFT) b_shift<R, D, NB>(q, c, axis, np, flags);
   if (stages & HK_STAGE_REPOSITION) qd_reposition<R, D, NB>(q, flags);
   if (stages & HK_STAGE_NEWTON) {
-    if constexpr (NB > kQuadDppSlots) qd_newton_lds<M, CW, R, D, NB>(q, cmine, j, slots_end);
-    else qd_newton<R, D, NB>(q, j);
+    if constexpr (NB > kQuadDppSlots) {
+      if (tsc) qd_newton_two_level<M, CW, R, D, NB>(q, cmine, tsc, j, slots_end);
+      else qd_newton_lds<M, CW, R, D, NB>(q, cmine, j, slots_end);
+    } else {
+      qd_newton<R, D, NB>(q, j);
+    }
     if constexpr (NB <= kQuadDppSlots)
       if (sorted) qd_ranks_first<R, D, NB>(q, rank);
   }
@@ -536,14 +663,14 @@ struct QuadStagesFor {
   using G = QuadGeom<M, D>;
   static __device__ __forceinline__ int run(float (&q)[G::R * D], int smax, const float (&c)[D], int axis, int np,
                                             int j, unsigned flags, unsigned stages, float* cmine, bool sorted,
-                                            int (&rank)[G::R]) {
+                                            int (&rank)[G::R], uint8_t* tsc = nullptr) {
     const int slots_end = kQuad * smax < M ? kQuad * smax : M;
     if constexpr (NB >= G::R) {
-      return qd_stages<M, G::CW, G::R, D, G::R>(q, c, axis, np, j, flags, stages, cmine, slots_end, sorted, rank);
+      return qd_stages<M, G::CW, G::R, D, G::R>(q, c, axis, np, j, flags, stages, cmine, slots_end, sorted, rank, tsc);
     } else {
       if (smax <= NB)
-        return qd_stages<M, G::CW, G::R, D, NB>(q, c, axis, np, j, flags, stages, cmine, slots_end, sorted, rank);
-      return QuadStagesFor<M, D, G::next_bucket(NB)>::run(q, smax, c, axis, np, j, flags, stages, cmine, sorted, rank);
+        return qd_stages<M, G::CW, G::R, D, NB>(q, c, axis, np, j, flags, stages, cmine, slots_end, sorted, rank, tsc);
+      return QuadStagesFor<M, D, G::next_bucket(NB)>::run(q, smax, c, axis, np, j, flags, stages, cmine, sorted, rank, tsc);
     }
   }
 };
@@ -677,6 +804,8 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void 
   using MaskM = MaskT<M>;
   __shared__ __align__(16) float lds_all[WPB * G::kRegion];
   __shared__ float cbuf_all[WPB * kQuadGames * D];  // slow path only
+  // large games: scratch of the two-level domination test (slot indices + verdicts, 2 x 64 bytes per game)
+  __shared__ __align__(16) uint8_t tsc_all[(G::kBig && M <= 64) ? WPB * kQuadGames * 128 : 16];
   // the wave index as a scalar: the slab's addresses, the LDS region and the game count stay in SGPRs
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & (kWave - 1);
   float* image = lds_all + wave * G::kRegion;
@@ -1022,7 +1151,8 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void 
     }
 #endif
     int rank[R];
-    np = QuadStagesFor<M, D, 1>::run(q, smax, c, axis_in, np, j, flags, stages, cmine, false, rank);
+    uint8_t* tsc = (G::kBig && M <= 64) ? tsc_all + (wave * kQuadGames + gi) * 128 : nullptr;
+    np = QuadStagesFor<M, D, 1>::run(q, smax, c, axis_in, np, j, flags, stages, cmine, false, rank, tsc);
   }
   const bool done = np < 2;
   if (leader) {  // (scalar base + the lane's game index: no 64-bit address arithmetic per output)

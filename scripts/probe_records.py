@@ -28,18 +28,19 @@ def timed(fn, min_s=0.03, seg=8):
     t = sorted(e[k].elapsed_time(e[k + 1]) / 1e3 / n for k in range(seg))
     return 0.5 * (t[seg // 2 - 1] + t[seg // 2])
 
-shapes = ((65536, 20, 3), (8192, 20, 3), (262144, 20, 3), (65536, 50, 4))
-for b, m, d in shapes:
-    P = ops.generate_points(b, m, d, 20, seed=42)
-    Q = torch.empty_like(P)
-    for rec in ((), ("host_class", "axis", "done", "reward"), ("obs", "host_class", "axis", "done", "reward", "game_length")):
-        out = []
-        for name, fl in (("default", 0), ("four", A.HK_FLAG_FORCE_FOUR_LANES), ("two", A.HK_FLAG_FORCE_TWO_LANES),
-                         ("one", A.HK_FLAG_FORCE_ONE_LANE)):
-            reps = 5
-            def ep():
-                for _ in range(reps):
-                    ops.rollout(Q, 20, 1, initial=P, record=rec, flags=fl)
-            out.append(f"{name} {timed(ep) / reps * 1e6:8.1f} us")
-        nbytes = b * 20 * (m * d * 4 if "obs" in rec else 0)
-        print(f"b={b} ({m},{d}) record={len(rec)} fields: " + "  ".join(out) + (f"   (obs {nbytes/1e6:.0f} MB)" if nbytes else ""), flush=True)
+if __name__ == "__main__":
+  shapes = ((65536, 20, 3), (8192, 20, 3), (262144, 20, 3), (65536, 50, 4))
+  for b, m, d in shapes:
+      P = ops.generate_points(b, m, d, 20, seed=42)
+      Q = torch.empty_like(P)
+      for rec in ((), ("host_class", "axis", "done", "reward"), ("obs", "host_class", "axis", "done", "reward", "game_length")):
+          out = []
+          for name, fl in (("default", 0), ("four", A.HK_FLAG_FORCE_FOUR_LANES), ("two", A.HK_FLAG_FORCE_TWO_LANES),
+                           ("one", A.HK_FLAG_FORCE_ONE_LANE)):
+              reps = 5
+              def ep():
+                  for _ in range(reps):
+                      ops.rollout(Q, 20, 1, initial=P, record=rec, flags=fl)
+              out.append(f"{name} {timed(ep) / reps * 1e6:8.1f} us")
+          nbytes = b * 20 * (m * d * 4 if "obs" in rec else 0)
+          print(f"b={b} ({m},{d}) record={len(rec)} fields: " + "  ".join(out) + (f"   (obs {nbytes/1e6:.0f} MB)" if nbytes else ""), flush=True)
