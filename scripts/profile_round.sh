@@ -1,14 +1,15 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): rocprofv3 kernel trace + separate PMC passes of bench.py and a kernel trace of
 # the search workload; raw CSVs under gpurun_out/, then scripts/summarise_profile.py condenses them into profiles/.
-# usage: scripts/profile_round.sh r02
+# usage: scripts/profile_round.sh r03
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-search --no-overlap > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
+# (the driver's own command line: --steps 20 --warmup 5)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-search --no-overlap > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 echo "trace exit $?"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/search" -- python3 "$ROOT/scripts/profile_search.py" > "$OUT/search.log" 2>&1
 echo "search trace exit $?"

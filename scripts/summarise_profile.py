@@ -17,7 +17,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -26,6 +26,7 @@ os.makedirs(dst, exist_ok=True)
 ROLLOUT = (re.compile(r"duo_kernel<20, 3, 1, 1>"), "131072")   # fused rollout, 65 536 games, two lanes per game
 STEP = (re.compile(r"quad_kernel<20, 3, 1, \d, 1(, false)?>"), "262144")  # hk_step (JAX-trainer configuration, f32 mask + i32 axis)
 STEP3 = (re.compile(r"quad_kernel<50, 4, 1, \d, 1(, false)?>"), "1048576")  # hk_step at (50,4) x 262 144
+ROLL3 = (re.compile(r"quadroll_kernel<50, 4, 1, 1(, false)?>"), "1048576")  # fused rollout at (50,4) x 262 144
 
 
 def short(name):
@@ -33,9 +34,15 @@ def short(name):
 
 
 def split_rollout(durs):
-    """dispatches of the rollout kernel at one grid size: fused 20-step episodes vs single steps"""
+    """dispatches of the rollout kernel at one grid size: fused 20-step episodes vs single steps.  Two clusters are
+    told apart at the geometric mean of the 10th and 90th percentile (an outlier dispatch must not move the cut);
+    one cluster (p90 < 1.6 x p10) is all episodes or all steps -- episodes if at least 15 ns per game."""
     v = np.asarray(durs, dtype=float)
-    cut = 0.6 * v.max()
+    lo, hi = np.percentile(v, 10), np.percentile(v, 90)
+    if hi < 1.6 * lo:
+        whole = np.ones(len(v), bool)
+        return (whole, ~whole) if np.median(v) > 15e3 else (~whole, whole)
+    cut = float(np.sqrt(lo * hi))
     return v > cut, v <= cut
 
 
@@ -145,7 +152,9 @@ out = {"source": f"rocprofv3 --pmc passes (separate runs), profiles/{tag}_pmc_su
        "boundary_step_bytes_per_launch": traffic(STEP),
        "boundary_step_valu_insts_per_launch": find(STEP, "", "SQ_INSTS_VALU"),
        "boundary_step_wait_any_frac": (find(STEP, "", "SQ_WAIT_ANY") or 0) / (find(STEP, "", "SQ_WAVE_CYCLES") or 1),
-       "config3_step_bytes_per_launch": traffic(STEP3)}
+       "config3_step_bytes_per_launch": traffic(STEP3),
+       "config3_rollout_bytes_per_launch": traffic(ROLL3),
+       "config3_rollout_valu_insts_per_launch": find(ROLL3, "", "SQ_INSTS_VALU")}
 
 # ---- share of the GPU time of the search workload spent in this package's HIP kernels ----------------------------
 sstats = first("search/**/*kernel_stats.csv")
