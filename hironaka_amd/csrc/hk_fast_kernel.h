@@ -318,6 +318,35 @@ __device__ inline void fast_policy(const Params& prm, uint64_t gg, uint32_t step
   fast_policy<D>(prm.seed, prm.host_policy, prm.agent_policy, gg, step, cache, cls, axis, mask, zeillinger_cls);
 }
 
+// ---- the policy stream off the critical path (plain rollouts; see hk_duo_kernel.h) ------------------------------------
+// A window of kFastPreBlocks Philox blocks per game (24 steps) is computed before the first step -- while the wave
+// would otherwise only wait for its slab --, two independent chains at a time, DECODED (subset mask | axis << 5) and
+// parked in LDS, one byte per game and step; a step reads its byte.  Episodes longer than a window refill it between
+// two passes over the staircase.
+constexpr int kFastPreBlocks = 12;
+
+template <int D>
+__device__ __forceinline__ void fast_policy_fill(uint8_t* act, uint64_t gg, uint32_t wb0, int nb, uint64_t seed,
+                                                 int host_policy, int agent_policy, int lane) {
+  static_assert(D <= 5, "an action travels as a byte");
+#pragma nounroll
+  for (int i = 0; i < kFastPreBlocks; i += 2) {
+    if (i >= nb) break;  // wave-uniform
+    const U4 r0 = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), wb0 + (uint32_t)i, kStreamPolicy, seed);
+    const U4 r1 = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), wb0 + (uint32_t)i + 1u, kStreamPolicy, seed);
+    int cls, axis;
+    uint32_t mask;
+    policy_from_words<D>(r0.x, r0.y, host_policy, agent_policy, cls, axis, mask, 0);
+    act[(2 * i) * kWave + lane] = (uint8_t)(mask | ((uint32_t)axis << 5));
+    policy_from_words<D>(r0.z, r0.w, host_policy, agent_policy, cls, axis, mask, 0);
+    act[(2 * i + 1) * kWave + lane] = (uint8_t)(mask | ((uint32_t)axis << 5));
+    policy_from_words<D>(r1.x, r1.y, host_policy, agent_policy, cls, axis, mask, 0);
+    act[(2 * i + 2) * kWave + lane] = (uint8_t)(mask | ((uint32_t)axis << 5));
+    policy_from_words<D>(r1.z, r1.w, host_policy, agent_policy, cls, axis, mask, 0);
+    act[(2 * i + 3) * kWave + lane] = (uint8_t)(mask | ((uint32_t)axis << 5));
+  }
+}
+
 // ---- the kernel: MODE is one of kModeStep / kModeRollout / kModeRolloutRec / kModeGenerate -------
 // HOT: a rollout configuration as compile-time constants.  kHotJax: the JAX trainer's rollouts (shift +
 // reposition + Newton polytope, JAX semantics without behaviour flags, uniformly random host and agent);
@@ -336,6 +365,9 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   using G = FastGeom<M, D>;
   __shared__ __align__(16) float lds[kWave * G::S];
   __shared__ float cbuf[kWave * D];  // slow path only: subset mask / row scratch per lane
+  // plain rollouts on the shapes a byte per action serves: the decoded actions of a window of steps (fast_policy_fill)
+  constexpr bool kWindow = MODE == kModeRollout && D <= 5;
+  __shared__ __align__(16) uint8_t pol[kWindow ? 2 * kFastPreBlocks * kWave : 16];
   constexpr bool kRec = MODE == kModeRolloutRec;            // rollout + per-step observations / records
   constexpr bool kRoll = MODE == kModeRollout || kRec;
   constexpr bool kStep = MODE == kModeStep || MODE == kModeStepAux;  // Aux: features / Zeillinger's class
@@ -350,6 +382,19 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   SlabRegs<M, D> slab;
   if (MODE != kModeGenerate) fast_slab_issue<M, D>(slab, in0, in_stride0, g0, ngames, lane);
   const uint64_t gg = prm.game_offset + (uint64_t)g;
+  // plain rollouts: the first window of decoded actions, computed while the slab is in flight (Zeillinger's host reads
+  // the state: its rollouts keep the policies in the loop and never look at the window)
+  uint32_t pol_b0 = prm.step_offset >> 1;  // first Philox block of the window (wave-uniform)
+  const uint32_t pol_last = (prm.steps > 0) ? (prm.step_offset + (uint32_t)prm.steps - 1u) >> 1 : pol_b0;
+  if constexpr (kWindow) {
+    if (HOT || prm.host_policy != HK_HOST_ZEILLINGER) {
+      const uint32_t nb = pol_last - pol_b0 + 1u;
+      fast_policy_fill<D>(pol, gg, pol_b0, (int)(nb < (uint32_t)kFastPreBlocks ? nb : (uint32_t)kFastPreBlocks), prm.seed,
+                          HOT ? (int)HK_HOST_RANDOM : prm.host_policy,
+                          (HOT == kHotJax) ? (int)HK_AGENT_RANDOM
+                                           : (HOT == kHotTorch) ? (int)HK_AGENT_RANDOM_LEGAL : prm.agent_policy, lane);
+    }
+  }
   float* mine = lds + lane * G::S;
   const float pad = (float)prm.pad;
   const unsigned flags = (HOT == kHotJax) ? (unsigned)HK_SEM_JAX : (HOT == kHotTorch) ? kHotTorchFlags : prm.flags;
@@ -519,48 +564,71 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
     static_assert(G::C <= 8 || G::C % 2 == 0, "bucket ladder: 1..8, then even numbers");
     int t = 0;
     bool stop = false;
-    RowLevels<G::C>::run([&](auto nbc, auto loc) {
-      constexpr int NB = decltype(nbc)::value, LO = decltype(loc)::value;
-      while (t < nsteps && (nmax > LO || LO == 0) && !stop) {  // (a wave of empty games has nmax 0: the last loop's)
-        int axis, cls;
-        uint32_t mask;
-        fast_policy<D>(seed, host_policy, agent_policy, gg, step0 + (uint32_t)t, pcache, cls, axis, mask, 0);
-        // (end_sort: the last step's rescale waits until the rows are ranked, after the loop)
-        const unsigned st = (end_sort && t + 1 == nsteps) ? (stages & ~(unsigned)HK_STAGE_RESCALE) : stages;
-        rescale_pending = end_sort && t + 1 == nsteps && (stages & HK_STAGE_RESCALE);
-        np = b_stages<G::C, D, NB, true>(q, c, axis, np, flags, st, mask);
-        if (!active) np = 2;
-        const bool done = np < 2;
-        if (done && length < 0) length = t + 1;
-        const unsigned long long bd = __ballot(active && done);
-        if (count_slot && lane == 0) count_add(count_slot + (size_t)(t + 1) * count_stride, (uint32_t)__popcll(bd));
-        if constexpr (NB == 1) {
-          // Fixed point (see hk_duo_kernel.h): once every game of the wave is down to one point at the origin (or
-          // none) nothing changes any more; the rest of the episode is the finished-game counts, in closed form.
-          if (bd == __ballot(active) && t + 1 < nsteps) {
-            bool still = true;
+    while (t < nsteps && !stop) {  // one pass per window of actions (episodes of up to 24 steps: one pass)
+      int tw = nsteps;
+      if constexpr (kWindow) {
+        if ((uint32_t)((step0 + (uint32_t)t) >> 1) - pol_b0 >= (uint32_t)kFastPreBlocks) {
+          __syncthreads();
+          pol_b0 = (step0 + (uint32_t)t) >> 1;
+          const uint32_t nb = pol_last - pol_b0 + 1u;
+          fast_policy_fill<D>(pol, gg, pol_b0, (int)(nb < (uint32_t)kFastPreBlocks ? nb : (uint32_t)kFastPreBlocks), seed,
+                              host_policy, agent_policy, lane);
+          __syncthreads();
+        }
+        const uint32_t wend_abs = (pol_b0 + (uint32_t)kFastPreBlocks) << 1;  // last step (exclusive) the window covers
+        tw = (wend_abs - step0 < (uint32_t)nsteps) ? (int)(wend_abs - step0) : nsteps;
+      }
+      RowLevels<G::C>::run([&](auto nbc, auto loc) {
+        constexpr int NB = decltype(nbc)::value, LO = decltype(loc)::value;
+        while (t < tw && (nmax > LO || LO == 0) && !stop) {  // (a wave of empty games has nmax 0: the last loop's)
+          int axis, cls;
+          uint32_t mask;
+          if constexpr (kWindow) {
+            const uint32_t a = pol[(int)(step0 + (uint32_t)t - (pol_b0 << 1)) * kWave + lane];
+            mask = a & 31u;
+            axis = (int)(a >> 5);
+          } else {
+            fast_policy<D>(seed, host_policy, agent_policy, gg, step0 + (uint32_t)t, pcache, cls, axis, mask, 0);
+          }
+          // (end_sort: the last step's rescale waits until the rows are ranked, after the loop)
+          const unsigned st = (end_sort && t + 1 == nsteps) ? (stages & ~(unsigned)HK_STAGE_RESCALE) : stages;
+          rescale_pending = end_sort && t + 1 == nsteps && (stages & HK_STAGE_RESCALE);
+          np = b_stages<G::C, D, NB, true>(q, c, axis, np, flags, st, mask);
+          if (!active) np = 2;
+          const bool done = np < 2;
+          if (done && length < 0) length = t + 1;
+          // (the finished-game counts: ballots over the games' first finished steps after the loop -- a finished game
+          // stays finished --, not an atomic per step in here)
+          if constexpr (NB == 1) {
+            // Fixed point (see hk_duo_kernel.h): once every game of the wave is down to one point at the origin (or
+            // none) nothing changes any more
+            if (t + 1 < nsteps && !__any(active && !done)) {
+              bool still = true;
 #pragma unroll
-            for (int k = 0; k < D; ++k) still &= (q[k] == 0.0f);
-            still |= !(q[0] < INFINITY);
-            if (!__any(active && !still)) {
-              if (count_slot && lane == 0)
-                for (int tt = t + 1; tt < nsteps; ++tt)
-                  count_add(count_slot + (size_t)(tt + 1) * count_stride, (uint32_t)__popcll(bd));
-              stop = true;
+              for (int k = 0; k < D; ++k) still &= (q[k] == 0.0f);
+              still |= !(q[0] < INFINITY);
+              if (!__any(active && !still)) stop = true;
+            }
+          } else {
+            // re-gather when the widest game of the wave got narrower (removed rows are holes until then)
+            if (t + 1 < nsteps && !__any(active && np >= nmax)) {
+              gmask = scatter_rows<M, G::C, D, NB>(q, mine, gmask, nmax);
+              const int nprev = nmax;
+              nmax = wave_max(active ? np : 0, nmax - 1);
+              gather_rows<M, G::C, D, NB>(q, mine, gmask, nprev);  // rows [nmax, nprev) become holes again
             }
           }
-        } else {
-          // re-gather when the widest game of the wave got narrower (removed rows are holes until then)
-          if (t + 1 < nsteps && !__any(active && np >= nmax)) {
-            gmask = scatter_rows<M, G::C, D, NB>(q, mine, gmask, nmax);
-            const int nprev = nmax;
-            nmax = wave_max(active ? np : 0, nmax - 1);
-            gather_rows<M, G::C, D, NB>(q, mine, gmask, nprev);  // rows [nmax, nprev) become holes again
-          }
+          ++t;
         }
-        ++t;
+      });
+    }
+    if (count_slot) {  // games whose first finished step is <= s, for every step s >= 1 (s = 0 was counted at entry)
+#pragma nounroll
+      for (int sidx = 1; sidx <= nsteps; ++sidx) {
+        const unsigned long long bf = __ballot(active && length >= 0 && length <= sidx);
+        if (lane == 0 && bf) count_add(count_slot + (size_t)sidx * count_stride, (uint32_t)__popcll(bf));
       }
-    });
+    }
   }
   for (int t = 0; !staircase && t < nsteps; ++t) {  // single steps, recording rollouts, the aux step modes, Zeillinger
     int axis = -1, cls = 0;
