@@ -818,6 +818,10 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void 
   const bool active = gi < ngames;
   const bool leader = active && j == 0;
   const int64_t g = g0 + gi;
+#ifdef HK_QUAD_PROBE  // (HK_QUAD_CUT=9: a time line per wave, written over num_points_out: scripts/probe_step_timeline.py)
+  const long long tl0 = wall_clock64();
+  long long tl1 = 0, tl2 = 0;
+#endif
   quad_slab_load<M, D>(in0 + g0 * G::N, image, ngames, lane);
   float* mine = image + gi * G::N;
   const float pad = prm.pad_f32;
@@ -838,6 +842,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void 
   }
   wave_lds_fence();
 #ifdef HK_QUAD_PROBE  // dev builds only (scripts/build_probe.sh): stop after a phase to see what each one costs
+  tl1 = wall_clock64();
   const int cut = prm.lds_stride;
   if (cut == 1) {
     quad_slab_store<M, D>(image, (float*)prm.out + g0 * G::N, ngames, lane);
@@ -1233,8 +1238,28 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void 
     }
   }
   wave_lds_fence();
+#ifdef HK_QUAD_PROBE
+  tl2 = wall_clock64();
+#endif
   quad_slab_store<M, D>(image, (float*)prm.out + g0 * G::N, ngames, lane);
   if constexpr (FEAT) quad_slab_store<M, D>(compact, prm.feat_out + g0 * G::N, ngames, lane);
+#ifdef HK_QUAD_PROBE
+  if (cut == 9 && prm.num_points_out && ngames == kQuadGames) {
+    wait_vmem_all();  // the slab's stores have left the wave
+    const long long tl3 = wall_clock64();
+    if (lane == 0) {
+      int32_t* w = prm.num_points_out + g0;
+      w[0] = (int32_t)tl0;
+      w[1] = (int32_t)tl1;
+      w[2] = (int32_t)tl2;
+      w[3] = (int32_t)tl3;
+      w[4] = smax;
+      w[5] = (int32_t)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+      w[6] = (int32_t)blockIdx.x;
+      w[7] = wave;
+    }
+  }
+#endif
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------

@@ -34,6 +34,8 @@ def check_line(out, n):
     r = out["roofline"]
     assert r["bound"] == "valu_issue" and (r["frac"] is None or 0 < r["frac"] <= 1)
     assert 0.9 < out["ms_per_step"] / out["ms_per_step_median"] < 1.5
+    if n > 1:  # the trainer-boundary gather follows every region and is timed with its own events
+        assert out["gather_us"] > 0 and out["gather_bytes_per_rank"] == n * 65536 * 60 * 4
 
 
 def test_bench_single_rank_line():

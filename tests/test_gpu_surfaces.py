@@ -377,6 +377,23 @@ def test_compute_rho_fused_equals_stepwise():
     assert rho == pytest.approx(rho_from_details(det)) and 0 < rho < 1
 
 
+@pytest.mark.parametrize("loops", [1, 2, 3, 5])
+def test_compute_rho_two_streams_equal_the_oracle(loops):
+    """compute_rho alternates its independent loops between two streams (one workspace of partial counts, one
+    reduction at the end): for 1 / 2 / an odd number of loops the histogram equals the sum of the oracle's per-loop
+    histograms -- the ordering of the workspace's zero fill, of both streams' launches and of the final reduction"""
+    kw = dict(spec=(20, 3), batch_size=1536, max_value=20, max_length=10, num_of_loops=loops, key=21)
+    for _ in range(2):  # (twice: the second call reuses cached workspaces / streams)
+        rho, det = compute_rho("random", "random_legal", **kw)
+        want = np.zeros(10, dtype=np.int64)
+        for loop in range(loops):
+            p0 = CO.generate_points(1536, 20, 3, 20, 21 + loop)
+            _, rec = CO.rollout(p0, 9, 21 + loop, agent_policy=A.HK_AGENT_RANDOM_LEGAL, record=False)
+            want += rec["done_count"].astype(np.int64)
+        assert det == details_from_done_counts(torch.as_tensor(want), 1536 * loops)
+        assert rho == pytest.approx(rho_from_details(det))
+
+
 def test_simulate_shapes_and_values():
     spec, b, T = (20, 3), 512, 20
     for role, obs_dim, act_dim in (("host", 60, 4), ("agent", 63, 3)):
