@@ -79,7 +79,7 @@ __device__ __forceinline__ void duo_slab_commit(DuoSlabRegs<M, D>& r, float* lds
 
 // kBatch: image chunks read per round (everything at once for the final store; fewer inside the recording loop,
 // whose register budget the rows own)
-template <int M, int D, bool CONTIG, int kBatch>
+template <int M, int D, bool CONTIG, int kBatch, bool NT = false>
 __device__ __forceinline__ void duo_store_slab_impl(const float* lds, float* base, int64_t out_stride, int ngames,
                                                     int lane) {
   using G = FastGeom<M, D>;
@@ -100,17 +100,23 @@ __device__ __forceinline__ void duo_store_slab_impl(const float* lds, float* bas
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
       const int q = lane + (i0 + u) * kWave;
-      if (i0 + u < QH && q < total) *reinterpret_cast<V*>(base + slab_chunk_global<M, D, CONTIG>(q, out_stride)) = v[u];
+      if (i0 + u < QH && q < total) {
+        V* dst = reinterpret_cast<V*>(base + slab_chunk_global<M, D, CONTIG>(q, out_stride));
+        if constexpr (NT) __builtin_nontemporal_store(v[u], dst);
+        else *dst = v[u];
+      }
     }
   }
 }
 
-template <int M, int D, int kBatch = DuoGeom<M, D>::QH>
+// NT: non-temporal stores -- a rollout's final state is written once and not read again by the launch: kept out of the
+// XCD's L2 it leaves the NEXT episode's initial states there (an episode restart re-reads them)
+template <int M, int D, int kBatch = DuoGeom<M, D>::QH, bool NT = false>
 __device__ inline void duo_store_slab(const float* lds, float* out, int64_t out_stride, int64_t g0, int ngames,
                                       int lane) {
   float* base = out + g0 * out_stride;
-  if (out_stride == FastGeom<M, D>::N) duo_store_slab_impl<M, D, true, kBatch>(lds, base, out_stride, ngames, lane);
-  else duo_store_slab_impl<M, D, false, kBatch>(lds, base, out_stride, ngames, lane);
+  if (out_stride == FastGeom<M, D>::N) duo_store_slab_impl<M, D, true, kBatch, NT>(lds, base, out_stride, ngames, lane);
+  else duo_store_slab_impl<M, D, false, kBatch, NT>(lds, base, out_stride, ngames, lane);
 }
 
 // ---- image <-> registers ----------------------------------------------------------------------------------
@@ -371,8 +377,8 @@ struct DuoLevels {
   }
 };
 
-// The policy stream of a pair: Philox block b (steps 2b, 2b + 1) is computed by the lane with (b & 1) == h only
-// -- one Philox per lane per FOUR steps -- and its two words reach the partner through DPP.
+// The policy stream of a pair: Philox block b (steps 4b .. 4b + 3, hk_common.h policy_words) is computed by the lane
+// with (b & 1) == h only -- one Philox per lane per EIGHT steps -- and its word reaches the partner through DPP.
 struct DuoPolicyCache {
   U4 r;
   uint32_t pair = 0xFFFFFFFFu;  // wave-uniform: `r` is block 2 * pair + h
@@ -380,52 +386,62 @@ struct DuoPolicyCache {
 
 __device__ inline void duo_policy_words(uint64_t gg, uint32_t step, uint64_t seed, DuoPolicyCache& cache, int h,
                                         uint32_t& host_word, uint32_t& agent_word) {
-  const uint32_t block = step >> 1, pair = block >> 1;
+  const uint32_t block = step >> 2, pair = block >> 1;
   if (cache.pair != pair) {
     cache.r = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), (pair << 1) | (uint32_t)h, kStreamPolicy, seed);
     cache.pair = pair;
   }
-  const uint32_t a = (step & 1u) ? cache.r.z : cache.r.x;
-  const uint32_t b = (step & 1u) ? cache.r.w : cache.r.y;
+  const uint32_t mine = u4_word(cache.r, step & 3u);
   const bool own = (int)(block & 1u) == h;
-  const uint32_t oa = (uint32_t)duo_other_i((int)a), ob = (uint32_t)duo_other_i((int)b);
-  host_word = own ? a : oa;
-  agent_word = own ? b : ob;
+  // (the exchange as a statement of its own, pinned by an empty asm: written inside the select the compiler ran the
+  // DPP move under the select's exec mask -- the partner lane inactive, its value read as zero)
+  uint32_t theirs = (uint32_t)duo_other_i((int)mine);
+  asm volatile("" : "+v"(theirs));
+  const uint32_t w = own ? mine : theirs;
+  host_word = w & 0xFFFF0000u;
+  agent_word = w << 16;
 }
 
 // ---- the policy stream off the critical path (plain rollouts) ------------------------------------------------------
 // A Philox block is ~115 instructions, 20 of them quarter-rate 32 x 32 -> 64 multiplies in a dependent chain of ten
 // rounds: computed inside the step loop (one block per lane every four steps) it was a fifth of the loop's
 // instructions and most of a late step's latency (a step on one slot per lane is ~40 instructions without it).  The
-// words depend on (game, step) only, not on the state: a WINDOW of kDuoPreBlocks blocks per game (24 steps) is
+// words depend on (game, step) only, not on the state: a WINDOW of kDuoPreBlocks blocks per game (24 steps: four per block) is
 // computed before the first step -- while the wave would otherwise only wait for its slab -- two independent chains at
 // a time, DECODED (subset mask, axis: the decode was another ~15 instructions of every step) and parked in LDS, one byte
 // per game and step; a step reads its byte (both lanes of a pair the same address).  Episodes longer than a window
 // refill it between two passes over the staircase.
-constexpr int kDuoPreBlocks = 12;
+constexpr int kDuoPreBlocks = 6;  // (a block serves four steps)
 
 // blocks [wb0, wb0 + nb) of the wave's games: lane (gi, h) computes blocks wb0 + h, wb0 + h + 2, ... and stores the
 // DECODED actions of their steps, one byte per game and step: subset mask (D bits) | axis << 5
 template <int D>
 __device__ __forceinline__ void duo_policy_fill(uint8_t* act, uint64_t gg, uint32_t wb0, int nb, uint64_t seed,
                                                 int host_policy, int agent_policy, int gi, int h) {
-  static_assert(D <= 5, "an action travels as a byte");
+  static_assert(D <= 5 && D <= kPolicyShortDim, "an action travels as a byte; four steps per Philox block");
+  auto put = [&](const U4& r, int b) {  // the four steps of block b
+    int cls, axis;
+    uint32_t mask;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t w = u4_word(r, k);
+      policy_from_words<D>(w & 0xFFFF0000u, w << 16, host_policy, agent_policy, cls, axis, mask, 0);
+      act[(4 * b + k) * kDuoGames + gi] = (uint8_t)(mask | ((uint32_t)axis << 5));
+    }
+  };
 #pragma nounroll
   for (int i = 0; i < kDuoPreBlocks; i += 4) {
     if (i >= nb) break;  // wave-uniform
     const int b0 = i + h, b1 = b0 + 2;
-    const U4 r0 = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), wb0 + (uint32_t)b0, kStreamPolicy, seed);
-    const U4 r1 = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), wb0 + (uint32_t)b1, kStreamPolicy, seed);
-    int cls, axis;
-    uint32_t mask;
-    policy_from_words<D>(r0.x, r0.y, host_policy, agent_policy, cls, axis, mask, 0);
-    act[(2 * b0) * kDuoGames + gi] = (uint8_t)(mask | ((uint32_t)axis << 5));
-    policy_from_words<D>(r0.z, r0.w, host_policy, agent_policy, cls, axis, mask, 0);
-    act[(2 * b0 + 1) * kDuoGames + gi] = (uint8_t)(mask | ((uint32_t)axis << 5));
-    policy_from_words<D>(r1.x, r1.y, host_policy, agent_policy, cls, axis, mask, 0);
-    act[(2 * b1) * kDuoGames + gi] = (uint8_t)(mask | ((uint32_t)axis << 5));
-    policy_from_words<D>(r1.z, r1.w, host_policy, agent_policy, cls, axis, mask, 0);
-    act[(2 * b1 + 1) * kDuoGames + gi] = (uint8_t)(mask | ((uint32_t)axis << 5));
+    if (i + 2 < nb) {  // (wave-uniform) two independent chains
+      const U4 r0 = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), wb0 + (uint32_t)b0, kStreamPolicy, seed);
+      const U4 r1 = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), wb0 + (uint32_t)b1, kStreamPolicy, seed);
+      put(r0, b0);
+      if (b1 < kDuoPreBlocks) put(r1, b1);
+    } else {  // the window's last one or two blocks
+      const U4 r0 = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), wb0 + (uint32_t)b0, kStreamPolicy, seed);
+      if (b0 < kDuoPreBlocks) put(r0, b0);
+    }
   }
 }
 
@@ -442,7 +458,7 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   __shared__ __align__(16) float lds[kDuoGames * G::S];
   __shared__ float cbuf[kDuoGames * D];  // slow path only
   // plain rollouts: the policy words of a window of steps (duo_policy_fill)
-  __shared__ __align__(16) uint8_t pol[(MODE == kModeRollout) ? 2 * kDuoPreBlocks * kDuoGames : 16];
+  __shared__ __align__(16) uint8_t pol[(MODE == kModeRollout) ? 4 * kDuoPreBlocks * kDuoGames : 16];
   const int lane = threadIdx.x;
   const int h = lane & 1, gi = lane >> 1;
   const int64_t g0 = (int64_t)blockIdx.x * kDuoGames;
@@ -462,8 +478,8 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   duo_slab_issue<M, D>(slab, in0, in_stride0, g0, ngames, lane);
   const uint64_t gg = prm.game_offset + (uint64_t)g;
   // plain rollouts: the first window of policy words, computed while the slab is in flight
-  uint32_t pol_b0 = prm.step_offset >> 1;  // first block of the window (wave-uniform)
-  const uint32_t pol_last = (prm.steps > 0) ? (prm.step_offset + (uint32_t)prm.steps - 1u) >> 1 : pol_b0;
+  uint32_t pol_b0 = prm.step_offset >> 2;  // first block of the window (wave-uniform)
+  const uint32_t pol_last = (prm.steps > 0) ? (prm.step_offset + (uint32_t)prm.steps - 1u) >> 2 : pol_b0;
   if constexpr (MODE == kModeRollout) {
     const uint32_t nb = pol_last - pol_b0 + 1u;
     duo_policy_fill<D>(pol, gg, pol_b0, (int)(nb < (uint32_t)kDuoPreBlocks ? nb : (uint32_t)kDuoPreBlocks), prm.seed,
@@ -601,16 +617,16 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
     int t = 0;
     bool stop = false;
     while (t < nsteps && !stop) {  // one pass per window of policy words (episodes of up to 24 steps: one pass)
-    if ((uint32_t)((step0 + (uint32_t)t) >> 1) - pol_b0 >= (uint32_t)kDuoPreBlocks) {
+    if ((uint32_t)((step0 + (uint32_t)t) >> 2) - pol_b0 >= (uint32_t)kDuoPreBlocks) {
       __syncthreads();
-      pol_b0 = (step0 + (uint32_t)t) >> 1;
+      pol_b0 = (step0 + (uint32_t)t) >> 2;
       const uint32_t nb = pol_last - pol_b0 + 1u;
       duo_policy_fill<D>(pol, gg, pol_b0, (int)(nb < (uint32_t)kDuoPreBlocks ? nb : (uint32_t)kDuoPreBlocks), seed,
                          host_policy, agent_policy, gi, h);
       __syncthreads();
     }
     // last step (exclusive) the window covers
-    const uint32_t wend_abs = (pol_b0 + (uint32_t)kDuoPreBlocks) << 1;
+    const uint32_t wend_abs = (pol_b0 + (uint32_t)kDuoPreBlocks) << 2;
     const int tw = (wend_abs - step0 < (uint32_t)nsteps) ? (int)(wend_abs - step0) : nsteps;
     DuoLevels<CH>::run([&](auto nbc, auto loc) {
       constexpr int NB = decltype(nbc)::value, LO = decltype(loc)::value;
@@ -632,7 +648,7 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
           if (t == 10) __builtin_amdgcn_s_setprio(3);
         }
 #endif
-        const uint32_t a = pol[(int)(step0 + (uint32_t)t - (pol_b0 << 1)) * kDuoGames + gi];
+        const uint32_t a = pol[(int)(step0 + (uint32_t)t - (pol_b0 << 2)) * kDuoGames + gi];
         const uint32_t mask = a & 31u;
         const int axis = (int)(a >> 5);
         const unsigned st = (end_sort && t + 1 == nsteps) ? (stages & ~(unsigned)HK_STAGE_RESCALE) : stages;
@@ -771,7 +787,7 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
     duo_scatter<M, CH, D>(q, mine, gmask, smax, h);
   }
   __syncthreads();
-  duo_store_slab<M, D>(lds, (float*)prm.out, prm.out_stride, g0, ngames, lane);
+  duo_store_slab<M, D, DuoGeom<M, D>::QH, (MODE == kModeRollout)>(lds, (float*)prm.out, prm.out_stride, g0, ngames, lane);
 #ifdef HK_DUO_PROBE
   if (kRoll && lane == 0 && prm.game_length_out && ngames >= 8) {
     int32_t* w = prm.game_length_out + g0;

@@ -143,7 +143,7 @@ __device__ __forceinline__ void fast_slab_commit(SlabRegs<M, D>& r, float* lds, 
 
 // Stores need no such care (nothing waits for them); the image is read a few chunks at a time so that a
 // store inside the rollout loop (per-step observations) adds little to the loop's register pressure.
-template <int M, int D, bool CONTIG, int kBatch>
+template <int M, int D, bool CONTIG, int kBatch, bool NT = false>
 __device__ __forceinline__ void fast_store_slab_impl(const float* lds, float* base, int64_t out_stride, int ngames,
                                                      int lane) {
   using G = FastGeom<M, D>;
@@ -162,20 +162,24 @@ __device__ __forceinline__ void fast_store_slab_impl(const float* lds, float* ba
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
       const int q = lane + (i0 + u) * kWave;
-      if (i0 + u < G::Q && q < total)
-        *reinterpret_cast<V*>(base + slab_chunk_global<M, D, CONTIG>(q, out_stride)) = v[u];
+      if (i0 + u < G::Q && q < total) {
+        V* dst = reinterpret_cast<V*>(base + slab_chunk_global<M, D, CONTIG>(q, out_stride));
+        if constexpr (NT) __builtin_nontemporal_store(v[u], dst);
+        else *dst = v[u];
+      }
     }
   }
 }
 
 // kBatch: image chunks read per round (4 inside the rollout loop; everything at once for the final store,
 // when the registers are free and the LDS latency would otherwise be paid once per round)
-template <int M, int D, int kBatch = 4>
+// (NT: non-temporal stores for a rollout's final state, see duo_store_slab)
+template <int M, int D, int kBatch = 4, bool NT = false>
 __device__ inline void fast_store_slab(const float* lds, float* out, int64_t out_stride, int64_t g0,
                                        int ngames, int lane) {
   float* base = out + g0 * out_stride;
-  if (out_stride == FastGeom<M, D>::N) fast_store_slab_impl<M, D, true, kBatch>(lds, base, out_stride, ngames, lane);
-  else fast_store_slab_impl<M, D, false, kBatch>(lds, base, out_stride, ngames, lane);
+  if (out_stride == FastGeom<M, D>::N) fast_store_slab_impl<M, D, true, kBatch, NT>(lds, base, out_stride, ngames, lane);
+  else fast_store_slab_impl<M, D, false, kBatch, NT>(lds, base, out_stride, ngames, lane);
 }
 
 // ---- image <-> registers --------------------------------------------------------------------------
@@ -308,7 +312,7 @@ __device__ inline void fast_policy(uint64_t seed, int host_policy, int agent_pol
                                    PolicyCache& cache, int& cls, int& axis, uint32_t& mask,
                                    int zeillinger_cls = 0) {
   uint32_t ra, rb;
-  policy_words(gg, step, seed, cache, ra, rb);
+  policy_words(gg, step, seed, cache, D, ra, rb);
   policy_from_words<D>(ra, rb, host_policy, agent_policy, cls, axis, mask, zeillinger_cls);
 }
 
@@ -319,16 +323,16 @@ __device__ inline void fast_policy(const Params& prm, uint64_t gg, uint32_t step
 }
 
 // ---- the policy stream off the critical path (plain rollouts; see hk_duo_kernel.h) ------------------------------------
-// A window of kFastPreBlocks Philox blocks per game (24 steps) is computed before the first step -- while the wave
+// A window of kFastPreBlocks Philox blocks per game (24 steps: four per block) is computed before the first step -- while the wave
 // would otherwise only wait for its slab --, two independent chains at a time, DECODED (subset mask | axis << 5) and
 // parked in LDS, one byte per game and step; a step reads its byte.  Episodes longer than a window refill it between
 // two passes over the staircase.
-constexpr int kFastPreBlocks = 12;
+constexpr int kFastPreBlocks = 6;  // (a block serves four steps: hk_common.h policy_words)
 
 template <int D>
 __device__ __forceinline__ void fast_policy_fill(uint8_t* act, uint64_t gg, uint32_t wb0, int nb, uint64_t seed,
                                                  int host_policy, int agent_policy, int lane) {
-  static_assert(D <= 5, "an action travels as a byte");
+  static_assert(D <= 5 && D <= kPolicyShortDim, "an action travels as a byte; four steps per Philox block");
 #pragma nounroll
   for (int i = 0; i < kFastPreBlocks; i += 2) {
     if (i >= nb) break;  // wave-uniform
@@ -336,14 +340,14 @@ __device__ __forceinline__ void fast_policy_fill(uint8_t* act, uint64_t gg, uint
     const U4 r1 = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), wb0 + (uint32_t)i + 1u, kStreamPolicy, seed);
     int cls, axis;
     uint32_t mask;
-    policy_from_words<D>(r0.x, r0.y, host_policy, agent_policy, cls, axis, mask, 0);
-    act[(2 * i) * kWave + lane] = (uint8_t)(mask | ((uint32_t)axis << 5));
-    policy_from_words<D>(r0.z, r0.w, host_policy, agent_policy, cls, axis, mask, 0);
-    act[(2 * i + 1) * kWave + lane] = (uint8_t)(mask | ((uint32_t)axis << 5));
-    policy_from_words<D>(r1.x, r1.y, host_policy, agent_policy, cls, axis, mask, 0);
-    act[(2 * i + 2) * kWave + lane] = (uint8_t)(mask | ((uint32_t)axis << 5));
-    policy_from_words<D>(r1.z, r1.w, host_policy, agent_policy, cls, axis, mask, 0);
-    act[(2 * i + 3) * kWave + lane] = (uint8_t)(mask | ((uint32_t)axis << 5));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t w0 = u4_word(r0, k), w1 = u4_word(r1, k);
+      policy_from_words<D>(w0 & 0xFFFF0000u, w0 << 16, host_policy, agent_policy, cls, axis, mask, 0);
+      act[(4 * i + k) * kWave + lane] = (uint8_t)(mask | ((uint32_t)axis << 5));
+      policy_from_words<D>(w1 & 0xFFFF0000u, w1 << 16, host_policy, agent_policy, cls, axis, mask, 0);
+      act[(4 * i + 4 + k) * kWave + lane] = (uint8_t)(mask | ((uint32_t)axis << 5));
+    }
   }
 }
 
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   __shared__ float cbuf[kWave * D];  // slow path only: subset mask / row scratch per lane
   // plain rollouts on the shapes a byte per action serves: the decoded actions of a window of steps (fast_policy_fill)
   constexpr bool kWindow = MODE == kModeRollout && D <= 5;
-  __shared__ __align__(16) uint8_t pol[kWindow ? 2 * kFastPreBlocks * kWave : 16];
+  __shared__ __align__(16) uint8_t pol[kWindow ? 4 * kFastPreBlocks * kWave : 16];
   constexpr bool kRec = MODE == kModeRolloutRec;            // rollout + per-step observations / records
   constexpr bool kRoll = MODE == kModeRollout || kRec;
   constexpr bool kStep = MODE == kModeStep || MODE == kModeStepAux;  // Aux: features / Zeillinger's class
@@ -384,8 +388,8 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   const uint64_t gg = prm.game_offset + (uint64_t)g;
   // plain rollouts: the first window of decoded actions, computed while the slab is in flight (Zeillinger's host reads
   // the state: its rollouts keep the policies in the loop and never look at the window)
-  uint32_t pol_b0 = prm.step_offset >> 1;  // first Philox block of the window (wave-uniform)
-  const uint32_t pol_last = (prm.steps > 0) ? (prm.step_offset + (uint32_t)prm.steps - 1u) >> 1 : pol_b0;
+  uint32_t pol_b0 = prm.step_offset >> 2;  // first Philox block of the window (wave-uniform)
+  const uint32_t pol_last = (prm.steps > 0) ? (prm.step_offset + (uint32_t)prm.steps - 1u) >> 2 : pol_b0;
   if constexpr (kWindow) {
     if (HOT || prm.host_policy != HK_HOST_ZEILLINGER) {
       const uint32_t nb = pol_last - pol_b0 + 1u;
@@ -567,15 +571,15 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
     while (t < nsteps && !stop) {  // one pass per window of actions (episodes of up to 24 steps: one pass)
       int tw = nsteps;
       if constexpr (kWindow) {
-        if ((uint32_t)((step0 + (uint32_t)t) >> 1) - pol_b0 >= (uint32_t)kFastPreBlocks) {
+        if ((uint32_t)((step0 + (uint32_t)t) >> 2) - pol_b0 >= (uint32_t)kFastPreBlocks) {
           __syncthreads();
-          pol_b0 = (step0 + (uint32_t)t) >> 1;
+          pol_b0 = (step0 + (uint32_t)t) >> 2;
           const uint32_t nb = pol_last - pol_b0 + 1u;
           fast_policy_fill<D>(pol, gg, pol_b0, (int)(nb < (uint32_t)kFastPreBlocks ? nb : (uint32_t)kFastPreBlocks), seed,
                               host_policy, agent_policy, lane);
           __syncthreads();
         }
-        const uint32_t wend_abs = (pol_b0 + (uint32_t)kFastPreBlocks) << 1;  // last step (exclusive) the window covers
+        const uint32_t wend_abs = (pol_b0 + (uint32_t)kFastPreBlocks) << 2;  // last step (exclusive) the window covers
         tw = (wend_abs - step0 < (uint32_t)nsteps) ? (int)(wend_abs - step0) : nsteps;
       }
       RowLevels<G::C>::run([&](auto nbc, auto loc) {
@@ -584,7 +588,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
           int axis, cls;
           uint32_t mask;
           if constexpr (kWindow) {
-            const uint32_t a = pol[(int)(step0 + (uint32_t)t - (pol_b0 << 1)) * kWave + lane];
+            const uint32_t a = pol[(int)(step0 + (uint32_t)t - (pol_b0 << 2)) * kWave + lane];
             mask = a & 31u;
             axis = (int)(a >> 5);
           } else {
@@ -731,7 +735,7 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
     scatter_rows<M, G::C, D>(q, mine, gmask, nmax);
   }
   __syncthreads();
-  fast_store_slab<M, D, G::Q>(lds, (float*)prm.out, prm.out_stride, g0, ngames, lane);
+  fast_store_slab<M, D, G::Q, (MODE == kModeRollout)>(lds, (float*)prm.out, prm.out_stride, g0, ngames, lane);
 }
 
 // ---- the specialisation table ------------------------------------------------------------------

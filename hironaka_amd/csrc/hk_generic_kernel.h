@@ -107,7 +107,7 @@ __device__ inline void choose_actions(const T* p, const Params& prm, uint64_t gg
   const uint32_t ncls = (1u << d) - (uint32_t)d - 1u;
   PolicyCache cache;
   uint32_t ra, rb;
-  policy_words(gg, step, prm.seed, cache, ra, rb);
+  policy_words(gg, step, prm.seed, cache, prm.d, ra, rb);
   if (prm.host_policy == HK_HOST_RANDOM) cls = (int)mulhi32(ra, ncls);
   else if (prm.host_policy == HK_HOST_ALL_COORD) cls = (int)ncls - 1;
   else cls = zeillinger_game(p, prm.m, d);

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(kPoolThreads, 2) void pool_kernel(const float* in0,
       dcache.r.w = ph[3];
     }
     // every live game ran step t0 - 1 in the round before (if there was one)
-    dcache.pair = (t0 > 0) ? (step0 + (uint32_t)(t0 - 1)) >> 2 : 0xFFFFFFFFu;
+    dcache.pair = (t0 > 0) ? (step0 + (uint32_t)(t0 - 1)) >> 3 : 0xFFFFFFFFu;  // (a pair of blocks: eight steps)
     HK_POOL_STAMP(0x300 | (live << 12) | round);
   }
   HK_POOL_STAMP(0x400);

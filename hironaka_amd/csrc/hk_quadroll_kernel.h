@@ -31,8 +31,8 @@
 
 namespace hk {
 
-constexpr int kQrBlocks = 12;              // Philox blocks per game in a window of actions (24 steps)
-constexpr int kQrSteps = 2 * kQrBlocks;
+constexpr int kQrBlocks = 6;               // Philox blocks per game in a window of actions (24 steps: four per block)
+constexpr int kQrSteps = 4 * kQrBlocks;
 
 template <int M, int D>
 struct QuadRollGeom {
@@ -125,19 +125,24 @@ __device__ __forceinline__ int qr_stages(float (&q)[R * D], uint32_t cmask, int 
 template <int D>
 __device__ __forceinline__ void qr_policy_fill(uint8_t* act, uint64_t gg0, uint32_t wb0, int nb, uint64_t seed,
                                                int host_policy, int agent_policy, int lane) {
+  static_assert(D <= kPolicyShortDim, "four steps per Philox block (hk_common.h policy_words)");
   const int game = lane & (kQuadGames - 1), sub = lane >> 4;
   const uint64_t gg = gg0 + (uint64_t)game;
 #pragma nounroll
   for (int i = 0; i < kQrBlocks; i += 4) {
     if (i >= nb) break;  // wave-uniform
     const int b = i + sub;
-    const U4 r = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), wb0 + (uint32_t)b, kStreamPolicy, seed);
-    int cls, axis;
-    uint32_t mask;
-    policy_from_words<D>(r.x, r.y, host_policy, agent_policy, cls, axis, mask, 0);
-    act[(2 * b) * kQuadGames + game] = (uint8_t)(mask | ((uint32_t)axis << 5));
-    policy_from_words<D>(r.z, r.w, host_policy, agent_policy, cls, axis, mask, 0);
-    act[(2 * b + 1) * kQuadGames + game] = (uint8_t)(mask | ((uint32_t)axis << 5));
+    if (b < kQrBlocks) {
+      const U4 r = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), wb0 + (uint32_t)b, kStreamPolicy, seed);
+      int cls, axis;
+      uint32_t mask;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t w = u4_word(r, k);
+        policy_from_words<D>(w & 0xFFFF0000u, w << 16, host_policy, agent_policy, cls, axis, mask, 0);
+        act[(4 * b + k) * kQuadGames + game] = (uint8_t)(mask | ((uint32_t)axis << 5));
+      }
+    }
   }
 }
 
@@ -273,8 +278,8 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   asm volatile("" : "+s"(step0), "+s"(seed), "+s"(host_policy), "+s"(agent_policy));
   // the first window of decoded actions, computed while the slab is in flight
   const uint64_t gg0 = prm.game_offset + (uint64_t)g0;
-  uint32_t wb0 = step0 >> 1;  // first Philox block of the window (wave-uniform)
-  const uint32_t wb_last = nsteps > 0 ? (step0 + (uint32_t)nsteps - 1u) >> 1 : wb0;
+  uint32_t wb0 = step0 >> 2;  // first Philox block of the window (wave-uniform)
+  const uint32_t wb_last = nsteps > 0 ? (step0 + (uint32_t)nsteps - 1u) >> 2 : wb0;
   {
     const uint32_t nb = wb_last - wb0 + 1u;
     qr_policy_fill<D>(act, gg0, wb0, (int)(nb < (uint32_t)kQrBlocks ? nb : (uint32_t)kQrBlocks), seed, host_policy,
@@ -475,15 +480,15 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   int t = 0;
   bool stop = false;
   while (t < nsteps && !stop) {  // one pass per window of actions (episodes of up to 24 steps: one pass)
-    if ((uint32_t)((step0 + (uint32_t)t) >> 1) - wb0 >= (uint32_t)kQrBlocks) {
+    if ((uint32_t)((step0 + (uint32_t)t) >> 2) - wb0 >= (uint32_t)kQrBlocks) {
       wave_lds_fence();
-      wb0 = (step0 + (uint32_t)t) >> 1;
+      wb0 = (step0 + (uint32_t)t) >> 2;
       const uint32_t nb = wb_last - wb0 + 1u;
       qr_policy_fill<D>(act, gg0, wb0, (int)(nb < (uint32_t)kQrBlocks ? nb : (uint32_t)kQrBlocks), seed, host_policy,
                         agent_policy, lane);
       wave_lds_fence();
     }
-    const uint32_t wstep0 = wb0 << 1;                       // first step of the window
+    const uint32_t wstep0 = wb0 << 2;                       // first step of the window
     const uint32_t wleft = wstep0 + (uint32_t)kQrSteps - step0;  // steps (from 0) the window reaches
     const int tw = (wleft < (uint32_t)nsteps) ? (int)wleft : nsteps;
     const uint8_t* arow = act + gi;
@@ -540,9 +545,9 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
     // every game of the wave at its fixed point before the last step: the state does not change any more, the records
     // go on (the same image as observation, the policies' draws, done, no reward)
     for (; t < nsteps; ++t) {
-      if ((uint32_t)((step0 + (uint32_t)t) >> 1) - wb0 >= (uint32_t)kQrBlocks) {
+      if ((uint32_t)((step0 + (uint32_t)t) >> 2) - wb0 >= (uint32_t)kQrBlocks) {
         wave_lds_fence();
-        wb0 = (step0 + (uint32_t)t) >> 1;
+        wb0 = (step0 + (uint32_t)t) >> 2;
         const uint32_t nb = wb_last - wb0 + 1u;
         qr_policy_fill<D>(act, gg0, wb0, (int)(nb < (uint32_t)kQrBlocks ? nb : (uint32_t)kQrBlocks), seed, host_policy,
                           agent_policy, lane);
@@ -550,11 +555,13 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
       }
       if (want_obs)
         quad_slab_store<M, D, true>(region, rec_obs + ((int64_t)t * rec_batch + g0) * G::N, ngames, lane);
-      const uint32_t a = act[(int)(step0 + (uint32_t)t - (wb0 << 1)) * kQuadGames + gi];
+      const uint32_t a = act[(int)(step0 + (uint32_t)t - (wb0 << 2)) * kQuadGames + gi];
       put_records(t, a, np < 2, np < 2);
     }
   }
-  quad_slab_store<M, D>(region, (float*)prm.out + g0 * G::N, ngames, lane);
+  // (non-temporal: the final state is written once and not read again by the launch -- kept out of the XCD's L2 it
+  // leaves the next episode's initial states there, hk_duo_kernel.h)
+  quad_slab_store<M, D, !REC>(region, (float*)prm.out + g0 * G::N, ngames, lane);
   // the finished-game counts: games whose first finished step is <= s, for every s (a finished game stays finished)
   if (prm.count_ws) {
     uint32_t* slot = prm.count_ws + blockIdx.x;
