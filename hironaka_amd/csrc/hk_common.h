@@ -196,6 +196,27 @@ __device__ __forceinline__ void count_add(uint32_t* slot, uint32_t v) {
   __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The per-step finished-game counts of a wave from its games' FIRST finished steps (a finished game stays finished: rows
+// are only ever removed): step s counts the games with 0 <= length <= s.  One ballot per step, the popcount parked in
+// lane s - base, and ONE atomic instruction per 64 steps (lane s adds to slot[s * stride]) -- as a loop of ballot + branch
+// + address + atomic per step this was ~1 us at the end of every wave's life.  `counted`: the lane speaks for a game
+// (one lane per game); steps first .. nsteps.
+__device__ __forceinline__ void add_length_counts(uint32_t* slot, uint32_t stride, int first, int nsteps, bool counted,
+                                                  int length, int lane) {
+  const unsigned ulen = counted ? (unsigned)length : 0xFFFFFFFFu;  // (-1 = never finished: above every step)
+  for (int base = first; base <= nsteps; base += kWave) {
+    uint32_t mine = 0;
+    const int top = nsteps < base + kWave - 1 ? nsteps : base + kWave - 1;
+#pragma nounroll
+    for (int s = base; s <= top; ++s) {
+      const unsigned long long b = __ballot(ulen <= (unsigned)s);
+      mine = (lane == s - base) ? (uint32_t)__popcll(b) : mine;
+    }
+    const int s = base + lane;
+    if (s <= nsteps && mine) count_add(slot + (size_t)s * stride, mine);
+  }
+}
+
 // The same fetch split in two, branch-free in the part that touches memory: `fetch_raw` requests the
 // aligned dword(s) holding element idx (the upper request repeats the lower one for elements narrower
 // than 8 bytes, so every address is inside the caller's array's own words), and nothing looks at the

@@ -487,6 +487,9 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
                        (HOT == kHotJax) ? (int)HK_AGENT_RANDOM
                                         : (HOT == kHotTorch) ? (int)HK_AGENT_RANDOM_LEGAL : prm.agent_policy, gi, h);
   }
+#ifdef HK_DUO_PROBE
+  if (lane == 0) probe_buf[21] = (int32_t)wall_clock64();  // the action window is filled
+#endif
   float* mine = lds + gi * G::S;
   const float pad = (float)prm.pad;
   const unsigned flags = (HOT == kHotJax) ? (unsigned)HK_SEM_JAX : (HOT == kHotTorch) ? kHotTorchFlags : prm.flags;
@@ -511,6 +514,9 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   duo_slab_commit<M, D>(slab, lds, ngames, lane);
   if (fetch_actions) fast_decode_actions<D>(prm, raw, c, axis_in);
   __syncthreads();
+#ifdef HK_DUO_PROBE
+  if (lane == 0) probe_buf[22] = (int32_t)wall_clock64();  // the slab is in LDS
+#endif
 
   // ---- live rows, exactness guard (both lanes of a pair scan the whole game) --------------------------------
   uint32_t gmask;
@@ -590,6 +596,15 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
 #pragma unroll
   for (int e = 0; e < CH * D; ++e) q[e] = INFINITY;
   duo_gather<M, CH, D>(q, mine, gmask, smax, h);
+#ifdef HK_DUO_PROBE
+  {
+    float sink = 0.0f;
+#pragma unroll
+    for (int e = 0; e < CH * D; ++e) sink += (q[e] < INFINITY) ? q[e] : 0.0f;
+    asm volatile("" : "+v"(sink));
+    if (lane == 0) probe_buf[23] = (int32_t)wall_clock64();  // the rows are in registers
+  }
+#endif
   if (!active) np = 2;
   int length = (np < 2) ? 0 : -1;
   if (kRoll && prm.count_ws) {
@@ -695,13 +710,8 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
     probe_steps = t;
     probe_t2 = wall_clock64();
 #endif
-    if (count_slot) {  // games whose first finished step is <= s, for every step s >= 1 (s = 0 was counted at entry)
-#pragma nounroll
-      for (int sidx = 1; sidx <= nsteps; ++sidx) {
-        const unsigned long long bf = __ballot(leader && length >= 0 && length <= sidx);
-        if (lane == 0 && bf) count_add(count_slot + (size_t)sidx * count_stride, (uint32_t)__popcll(bf));
-      }
-    }
+    // games whose first finished step is <= s, for every step s >= 1 (s = 0 was counted at entry)
+    if (count_slot) add_length_counts(count_slot, count_stride, 1, nsteps, leader, length, lane);
   }
   const bool want_obs = kRec && prm.obs_out != nullptr;
   const bool want_records = kRec && (prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out);

@@ -626,13 +626,8 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
         }
       });
     }
-    if (count_slot) {  // games whose first finished step is <= s, for every step s >= 1 (s = 0 was counted at entry)
-#pragma nounroll
-      for (int sidx = 1; sidx <= nsteps; ++sidx) {
-        const unsigned long long bf = __ballot(active && length >= 0 && length <= sidx);
-        if (lane == 0 && bf) count_add(count_slot + (size_t)sidx * count_stride, (uint32_t)__popcll(bf));
-      }
-    }
+    // games whose first finished step is <= s, for every step s >= 1 (s = 0 was counted at entry)
+    if (count_slot) add_length_counts(count_slot, count_stride, 1, nsteps, active, length, lane);
   }
   for (int t = 0; !staircase && t < nsteps; ++t) {  // single steps, recording rollouts, the aux step modes, Zeillinger
     int axis = -1, cls = 0;

@@ -563,15 +563,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   // leaves the next episode's initial states there, hk_duo_kernel.h)
   quad_slab_store<M, D, !REC>(region, (float*)prm.out + g0 * G::N, ngames, lane);
   // the finished-game counts: games whose first finished step is <= s, for every s (a finished game stays finished)
-  if (prm.count_ws) {
-    uint32_t* slot = prm.count_ws + blockIdx.x;
-    const uint32_t stride = prm.count_stride;
-#pragma nounroll
-    for (int s = 0; s <= nsteps; ++s) {
-      const unsigned long long b = __ballot(leader && length >= 0 && length <= s);
-      if (lane == 0 && b) count_add(slot + (size_t)s * stride, (uint32_t)__popcll(b));
-    }
-  }
+  if (prm.count_ws) add_length_counts(prm.count_ws + blockIdx.x, prm.count_stride, 0, nsteps, leader, length, lane);
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------

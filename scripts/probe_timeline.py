@@ -35,8 +35,14 @@ print("the ten last waves: block, start, slab, loop done, end, steps, smax")
 for i in late:
     print(f"  {blk[i]:5d} {us(t0)[i]:6.2f} {us(t1)[i]:6.2f} {us(t2)[i]:6.2f} {us(t3)[i]:6.2f} {steps[i]:3d} {smax[i]:2d}")
 
+# prologue stamps (probe build): action window filled / slab in LDS / (scan: t1) / rows in registers
+pa, pb, pg = (full[:, 8 + k] & 0xFFFFFFFF for k in (21, 22, 23))
+usp = lambda x: ((x - (base & 0xFFFFFFFF)) & 0xFFFFFFFF) / 100.0
+print("prologue (since the wave's start): window filled %.2f, slab in LDS %.2f, scanned %.2f, rows in registers %.2f; "
+      "epilogue (loop done -> end) %.2f" % ((usp(pa) - us(t0)).mean(), (usp(pb) - us(t0)).mean(), (us(t1) - us(t0)).mean(),
+                                              (usp(pg) - us(t0)).mean(), (us(t3) - us(t2)).mean()))
 # per-step stamps (probe build): time of each step and the slots per lane after it
-st = full[:, 8:28] & 0xFFFFFFFF
+st = full[:, 8:28] & 0xFFFFFFFF  # (entries 21 - 23 of the buffer hold the prologue stamps)
 clk = (st >> 4); sm = st & 15
 t1m = (t1 & 0x0FFFFFFF)
 print("step: mean duration [us] over the waves that ran it / mean slots per lane after it / share of waves whose slots shrank (re-deal)")
