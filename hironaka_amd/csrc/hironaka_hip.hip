@@ -79,14 +79,18 @@ static bool use_quad(const Params& prm, int dtype) {
   return quad_default(prm, device_simds());
 }
 // plain rollouts on four lanes per game (hk_quadroll_kernel.h): forced, or where it is the default
+static bool use_duo(const Params& prm) { return !(prm.flags & HK_FLAG_FORCE_ONE_LANE) && duo_wanted(prm); }
 static bool use_quadroll(const Params& prm, int dtype) {
   Params probe = prm;
   probe.flags &= ~(unsigned)HK_FLAG_FORCE_FOUR_LANES;
   if (!quadroll_supported(probe, dtype)) return false;
   if (prm.flags & HK_FLAG_FORCE_FOUR_LANES) return true;
-  return quadroll_default(prm, device_simds());
+  // the small records without observations ride on the two-lane plain rollout too (hk_duo_kernel.h: flush_records):
+  // where that is the faster plain kernel it takes them (28.8 -> ~23 us at (20,3) x 65 536)
+  const bool small_only = !prm.obs_out && (prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out);
+  const bool duo_takes = small_only && fast_supported(prm, dtype) && use_duo(prm);
+  return quadroll_default(prm, device_simds(), duo_takes);
 }
-static bool use_duo(const Params& prm) { return !(prm.flags & HK_FLAG_FORCE_ONE_LANE) && duo_wanted(prm); }
 // plain rollouts on the pool kernel (hk_pool_kernel.h): forced, or where it is ahead of the fixed deals
 static bool use_pool(const Params& prm) {
   if (!pool_supported(prm)) return false;

@@ -447,9 +447,12 @@ __device__ __forceinline__ void duo_policy_fill(uint8_t* act, uint64_t gg, uint3
 
 // ---- the kernel: fused rollouts (MODE kModeRollout; kModeRolloutRec: with per-step observations / records) and
 // single steps with the caller's actions (kModeStep: hk_step) -------------------------------------------------
-template <int M, int D, int MODE, int HOT = kHotNone>
+// ACTS (plain rollouts): the kernel also writes the small per-step records (flush_records below) -- its own
+// instantiation, the headline kernel carries none of it (measured: +0.4 us per 65 536-game episode as a run-time branch)
+template <int M, int D, int MODE, int HOT = kHotNone, bool ACTS = false>
 __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t in_stride0, int batch0,
                                                        const Params prm) {
+  static_assert(!ACTS || MODE == kModeRollout, "the small records ride on the plain rollout");
   constexpr bool kRec = MODE == kModeRolloutRec;
   constexpr bool kRoll = MODE == kModeRollout || kRec;
   using G = FastGeom<M, D>;
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
         const unsigned long long bd = __ballot(leader && done);
         if (lane == 0) count_add(prm.count_ws + (size_t)(t + 1) * prm.count_stride + blockIdx.x, (uint32_t)__popcll(bd));
       }
-      if (kRec && leader) {
+      if ((kRec || ACTS) && leader) {  // (ACTS: plain rollouts with the small records, flush_records below)
         const int64_t at = (int64_t)t * prm.batch + g;
         if (prm.r_host_class_out) prm.r_host_class_out[at] = cls;
         if (prm.r_axis_out) prm.r_axis_out[at] = axis;
@@ -623,6 +626,42 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   else
     asm volatile("" : "+s"(count_slot), "+s"(count_stride), "+s"(step0), "+s"(seed), "+s"(host_policy),
                  "+s"(agent_policy));
+  // Plain rollouts write the small records (host class, axis, done, reward) too, when asked: they are a function of the
+  // window's action bytes and of the game's first finished step, so no step stores them -- they go out per window
+  // (before it moves, and after the last step), lane = (step within a pair, game of the wave): 128-B runs per step and
+  // field (hk_quadroll_kernel.h does the same on 16 games).  Observations stay with kModeRolloutRec / the four-lane kernel.
+  static_assert(kDuoGames == 32 && kWave == 64, "flush_records: two steps of the wave's games per instruction");
+  int32_t* rec_cls = ACTS ? prm.r_host_class_out : nullptr;
+  int32_t* rec_axis = ACTS ? prm.r_axis_out : nullptr;
+  uint8_t* rec_done = ACTS ? prm.r_done_out : nullptr;
+  float* rec_reward = ACTS ? prm.r_reward_out : nullptr;
+  int64_t rec_batch = prm.batch;
+  float rec_sign = prm.reward_sign;
+  if constexpr (ACTS)  // (pinned: left to the compiler the stores' address arithmetic ends in an illegal VGPR -> SGPR copy)
+    asm volatile("" : "+s"(rec_cls), "+s"(rec_axis), "+s"(rec_done), "+s"(rec_reward), "+s"(rec_batch), "+s"(rec_sign));
+  constexpr bool want_small = ACTS;
+  int t_rec = 0;  // the records of steps < t_rec are written
+  auto flush_records = [&](int t_end) {  // (t_end: wave-uniform)
+    if (t_rec < t_end) {
+      const int gsel = lane & (kDuoGames - 1), sub = lane >> 5;
+      const int lg = __shfl(length, gsel * 2);  // the game's first finished step (0: from the start, -1: not yet)
+      const bool gok = gsel < ngames;
+      const int64_t off = (int64_t)sub * rec_batch + gsel;
+      const uint8_t* w = pol + (int)(step0 + (uint32_t)t_rec - (pol_b0 << 2)) * kDuoGames + lane;
+      for (int ta = t_rec; ta < t_end; ta += 2, w += 2 * kDuoGames) {
+        const int tt = ta + sub;
+        if (gok && tt < t_end) {
+          const uint32_t a = *w;
+          const int64_t row = (int64_t)ta * rec_batch + g0;  // (scalar)
+          if (rec_cls) (rec_cls + row)[off] = encode_mask(a & 31u);
+          if (rec_axis) (rec_axis + row)[off] = (int32_t)(a >> 5);
+          if (rec_done) (rec_done + row)[off] = lg >= 0 && tt + 1 >= lg;
+          if (rec_reward) (rec_reward + row)[off] = rec_sign * (float)(lg >= 1 && tt + 1 == lg);
+        }
+      }
+    }
+    t_rec = t_end;
+  };
   if constexpr (MODE == kModeRollout) {
     // ---- plain rollouts: a STAIRCASE of loops, one per bucket of slots per lane, entered from the top down.  smax
     // never grows, so the wave walks down the stairs once; each loop is straight-line for its own bucket -- no
@@ -633,6 +672,7 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
     bool stop = false;
     while (t < nsteps && !stop) {  // one pass per window of policy words (episodes of up to 24 steps: one pass)
     if ((uint32_t)((step0 + (uint32_t)t) >> 2) - pol_b0 >= (uint32_t)kDuoPreBlocks) {
+      if constexpr (want_small) flush_records(__builtin_amdgcn_readfirstlane(t));
       __syncthreads();
       pol_b0 = (step0 + (uint32_t)t) >> 2;
       const uint32_t nb = pol_last - pol_b0 + 1u;
@@ -712,6 +752,20 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
 #endif
     // games whose first finished step is <= s, for every step s >= 1 (s = 0 was counted at entry)
     if (count_slot) add_length_counts(count_slot, count_stride, 1, nsteps, leader, length, lane);
+    if constexpr (want_small) {  // window by window up to the last step (the loop may have left at a fixed point)
+      for (;;) {
+        const uint32_t wend = ((pol_b0 + (uint32_t)kDuoPreBlocks) << 2) - step0;  // steps (from 0) the window reaches
+        const int te = __builtin_amdgcn_readfirstlane((wend < (uint32_t)nsteps) ? (int)wend : nsteps);
+        flush_records(te);
+        if (te >= nsteps) break;
+        __syncthreads();
+        pol_b0 = (step0 + (uint32_t)te) >> 2;
+        const uint32_t nb = pol_last - pol_b0 + 1u;
+        duo_policy_fill<D>(pol, gg, pol_b0, (int)(nb < (uint32_t)kDuoPreBlocks ? nb : (uint32_t)kDuoPreBlocks), seed,
+                           host_policy, agent_policy, gi, h);
+        __syncthreads();
+      }
+    }
   }
   const bool want_obs = kRec && prm.obs_out != nullptr;
   const bool want_records = kRec && (prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out);
@@ -854,11 +908,19 @@ int launch_duo_t(Params prm, hipStream_t stream) {
   const unsigned grid = (unsigned)(((int64_t)prm.batch + kDuoGames - 1) / kDuoGames);
   prm.games_per_block = kDuoGames;
   launch_prepare();
-  const bool records = prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out;
+  // (the small records alone ride on the plain rollout kernels: ACTS)
+  const bool records = prm.obs_out != nullptr;
+  const bool acts = !records && (prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out);
   const int hot = (prm.mode == kModeRollout && !records) ? fast_hot_config(prm) : kHotNone;
   if (prm.mode == kModeRollout && records)
     hipLaunchKernelGGL((duo_kernel<M, D, kModeRolloutRec>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
                        prm.in_stride, prm.batch, prm);
+  else if (prm.mode == kModeRollout && acts && hot == kHotJax)
+    hipLaunchKernelGGL((duo_kernel<M, D, kModeRollout, kHotJax, true>), dim3(grid), dim3(kWave), 0, stream,
+                       (const float*)prm.in, prm.in_stride, prm.batch, prm);
+  else if (prm.mode == kModeRollout && acts)
+    hipLaunchKernelGGL((duo_kernel<M, D, kModeRollout, kHotNone, true>), dim3(grid), dim3(kWave), 0, stream,
+                       (const float*)prm.in, prm.in_stride, prm.batch, prm);
   else if (prm.mode == kModeStep && prm.flags == HK_SEM_JAX &&
            prm.stages == (HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON))
     // take_actions as the JAX trainer configures it (jax/util.py:83-125 with reposition, without rescale)

@@ -455,9 +455,10 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   // ---- the steps: a staircase of loops, one per bucket of slots per lane ---------------------------------------------
   const bool want_obs = REC && prm.obs_out != nullptr;
   const bool want_records = REC && (prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out);
-  // one step's records of the lane's game (leader lanes): `a` = the action byte, done / prev_done around the step.
-  // Addresses: a scalar row base (step * batch + the wave's first game) + the lane's game index as a 32-bit offset --
-  // no 64-bit address arithmetic per lane and store; the four pointers and the batch live in SGPRs.
+  // The small records are a function of the window of action bytes and of the game's first finished step, so no step
+  // stores them: they are written per window (before it moves, and at the end) -- lane = (step within a group of four,
+  // game of the wave), one byte of the window per lane, 64-B runs per step and field instead of one 16-lane store per
+  // step, field and wave.  (Round 2 stored them inside the step: 80 partial stores per wave and episode.)
   int32_t* rec_cls = REC ? prm.r_host_class_out : nullptr;
   int32_t* rec_axis = REC ? prm.r_axis_out : nullptr;
   uint8_t* rec_done = REC ? prm.r_done_out : nullptr;
@@ -467,20 +468,34 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   float rec_sign = prm.reward_sign;
   if constexpr (REC) asm volatile("" : "+s"(rec_cls), "+s"(rec_axis), "+s"(rec_done), "+s"(rec_reward), "+s"(rec_obs),
                                   "+s"(rec_batch), "+s"(rec_sign));
-  auto put_records = [&](int tt, uint32_t a, bool done, bool prev_done) {
-    if (want_records && leader) {
-      const int64_t row = (int64_t)tt * rec_batch + g0;  // (scalar)
-      const unsigned ug = (unsigned)gi;
-      if (rec_cls) (rec_cls + row)[ug] = encode_mask(a & 31u);
-      if (rec_axis) (rec_axis + row)[ug] = (int32_t)(a >> 5);
-      if (rec_done) (rec_done + row)[ug] = done;
-      if (rec_reward) (rec_reward + row)[ug] = rec_sign * (float)(done && !prev_done);
+  int t_rec = 0;  // the records of steps < t_rec are written
+  auto flush_records = [&](int t_end, int len_now) {
+    if (want_records && t_rec < t_end) {
+      const int gsel = lane & (kQuadGames - 1), sub = lane >> 4;
+      const int lg = __shfl(len_now, gsel * kQuad);  // the game's first finished step (0: from the start, -1: not yet)
+      const bool gok = gsel < ngames;
+      const int64_t off = (int64_t)sub * rec_batch + gsel;
+      const uint8_t* w = act + (int)(step0 + (uint32_t)t_rec - (wb0 << 2)) * kQuadGames + lane;
+      for (int ta = t_rec; ta < t_end; ta += 4, w += 4 * kQuadGames) {
+        const int tt = ta + sub;
+        if (gok && tt < t_end) {
+          const uint32_t a = *w;
+          const int64_t row = (int64_t)ta * rec_batch + g0;  // (scalar)
+          const bool done = lg >= 0 && tt + 1 >= lg;
+          if (rec_cls) (rec_cls + row)[off] = encode_mask(a & 31u);
+          if (rec_axis) (rec_axis + row)[off] = (int32_t)(a >> 5);
+          if (rec_done) (rec_done + row)[off] = done;
+          if (rec_reward) (rec_reward + row)[off] = rec_sign * (float)(lg >= 1 && tt + 1 == lg);
+        }
+      }
     }
+    t_rec = t_end;
   };
   int t = 0;
   bool stop = false;
   while (t < nsteps && !stop) {  // one pass per window of actions (episodes of up to 24 steps: one pass)
     if ((uint32_t)((step0 + (uint32_t)t) >> 2) - wb0 >= (uint32_t)kQrBlocks) {
+      if constexpr (REC) flush_records(t, length);
       wave_lds_fence();
       wb0 = (step0 + (uint32_t)t) >> 2;
       const uint32_t nb = wb_last - wb0 + 1u;
@@ -503,16 +518,21 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
         if constexpr (REC) {
           if (want_obs) {  // the state before the step
             qr_build_image<M, D, R>(q, orig, region, mine, smax, pad, lane);
-            quad_slab_store<M, D, true>(region, rec_obs + ((int64_t)t * rec_batch + g0) * G::N, ngames, lane);
+#if !defined(HK_QR_EXP) || HK_QR_EXP != 2
+            // (ordinary stores: 315 MB of non-temporal stores in this pattern take 61.6 us where ordinary ones take
+            // 55.5 and a plain fill 47 -- scripts/probe_obs_pattern.py; the L2 write-back combines, the stream does not)
+            quad_slab_store<M, D, false>(region, rec_obs + ((int64_t)t * rec_batch + g0) * G::N, ngames, lane);
+#endif
             wave_lds_fence();
           }
         }
-        const bool prev_done = np < 2;
+#if defined(HK_QR_EXP) && HK_QR_EXP == 1
+        if (!REC)
+#endif
         np = qr_stages<M, CW, R, D, NB>(q, cmask, axis, np, j, flags, stages, cmine, smax);
         if (!active) np = 2;
         const bool done = np < 2;
         if (done && length < 0) length = t + 1;
-        if constexpr (REC) put_records(t, a, done, prev_done);
         if constexpr (NB == 1) {
           // Fixed point (hk_duo_kernel.h): once every game of the wave is down to one point at the origin (or none)
           // nothing changes any more
@@ -542,10 +562,11 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   // ---- publish: padding everywhere, the survivors at their own rows ---------------------------------------------------
   qr_build_image<M, D, R>(q, orig, region, mine, smax, pad, lane);
   if constexpr (REC) {
-    // every game of the wave at its fixed point before the last step: the state does not change any more, the records
-    // go on (the same image as observation, the policies' draws, done, no reward)
+    // every game of the wave at its fixed point before the last step: the state does not change any more, the
+    // observations go on (the same image); the records of a window are written before it moves
     for (; t < nsteps; ++t) {
       if ((uint32_t)((step0 + (uint32_t)t) >> 2) - wb0 >= (uint32_t)kQrBlocks) {
+        flush_records(t, length);
         wave_lds_fence();
         wb0 = (step0 + (uint32_t)t) >> 2;
         const uint32_t nb = wb_last - wb0 + 1u;
@@ -554,10 +575,9 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
         wave_lds_fence();
       }
       if (want_obs)
-        quad_slab_store<M, D, true>(region, rec_obs + ((int64_t)t * rec_batch + g0) * G::N, ngames, lane);
-      const uint32_t a = act[(int)(step0 + (uint32_t)t - (wb0 << 2)) * kQuadGames + gi];
-      put_records(t, a, np < 2, np < 2);
+        quad_slab_store<M, D, false>(region, rec_obs + ((int64_t)t * rec_batch + g0) * G::N, ngames, lane);
     }
+    flush_records(nsteps, length);
   }
   // (non-temporal: the final state is written once and not read again by the launch -- kept out of the XCD's L2 it
   // leaves the next episode's initial states there, hk_duo_kernel.h)
@@ -626,9 +646,10 @@ inline bool quadroll_supported(const Params& prm, int dtype) {
 // Recording rollouts: at every size (scripts/probe_records.py, (20,3), per 20-step episode incl. the counter reduce:
 // 39.8 against 48.6 us with the small records and 69.5 against 82.1 us with the observations at 65 536 games, 90.6 / 240
 // against 114 / 279 us at 262 144).
-inline bool quadroll_default(const Params& prm, int simds) {
+inline bool quadroll_default(const Params& prm, int simds, bool small_records_elsewhere = false) {
   if (prm.m > 32) return true;
-  if (prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out) return true;
+  if (prm.obs_out) return true;
+  if ((prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out) && !small_records_elsewhere) return true;
   return ((int64_t)prm.batch + kQuadGames - 1) / kQuadGames <= (int64_t)2 * simds;
 }
 

@@ -161,6 +161,13 @@ def one_case(rng):
     if not (np.array_equal(Q2.cpu().numpy(), wp)
             and np.array_equal(plain["done_count"].cpu().numpy().astype(np.uint64), wrec["done_count"])):
         raise Mismatch(f"PLAIN ROLLOUT MISMATCH {cfg}")
+    # ... and with the small records alone (no observations): written per action window by the plain rollout kernels
+    small = ("host_class", "axis", "done", "reward", "game_length")
+    Q3 = P.clone()
+    rec3 = ops.rollout(Q3, T, seed, game_offset=off, host_policy=hp, agent_policy=apol, stages=rstages,
+                       flags=flags_p, padding_value=pad, record=small)
+    if not (np.array_equal(Q3.cpu().numpy(), wp) and all(np.array_equal(rec3[k].cpu().numpy(), wrec[k]) for k in small)):
+        raise Mismatch(f"SMALL RECORDS ROLLOUT MISMATCH {cfg}")
 
 
 def run_cases(count: int, seed: int) -> int:

@@ -420,6 +420,42 @@ def test_rollout_matches_oracle(spec, force_generic):
                     assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"])
 
 
+@pytest.mark.parametrize("spec", [(20, 3), (10, 3), (8, 4), (20, 4), (50, 4)])
+def test_small_records_without_observations_match_oracle(spec):
+    """The small per-step records alone (host class, axis, done, reward): the two-lane plain rollout writes them from
+    its action window and the games' first finished steps (`duo_kernel<..., ACTS>`), the four-lane kernel likewise; the
+    one-lane kernel stores them per step.  Episodes inside one window of 24 steps, across windows (50 steps from an odd
+    offset), a ragged last wave, one game off the exact path (a partly padded row: whole-wave slow path), both the
+    compiled JAX configuration and a run-time configured one."""
+    m, d = spec
+    p0 = CO.generate_points(32 * 5 + 7, m, d, 20, 11)
+    p0[40, 1, 0] = -1.0  # partly padded row: the wave of game 40 takes the generic routines
+    fields = ("host_class", "axis", "done", "reward", "game_length")
+    stages = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON
+    for hp, ap, st in ((A.HK_HOST_RANDOM, A.HK_AGENT_RANDOM, stages), (A.HK_HOST_RANDOM, A.HK_AGENT_RANDOM_LEGAL, None),
+                       (A.HK_HOST_ALL_COORD, A.HK_AGENT_CHOOSE_LAST, None)):
+        kw = dict(host_policy=hp, agent_policy=ap, **({"stages": st} if st is not None else {}))
+        for T, so in ((9, 3), (24, 0), (50, 5)):
+            want_p, want = CO.rollout(p0, T, 7, game_offset=3, step_offset=so, **kw)
+            for fl in (0, A.HK_FLAG_FORCE_TWO_LANES, A.HK_FLAG_FORCE_FOUR_LANES, A.HK_FLAG_FORCE_ONE_LANE):
+                if fl == A.HK_FLAG_FORCE_TWO_LANES and m > 32:
+                    continue
+                P = dev(p0.copy())
+                got = ops.rollout(P, T, 7, game_offset=3, step_offset=so, flags=fl, record=fields, **kw)
+                assert np.array_equal(host(P), want_p), (hp, ap, T, fl)
+                for k in fields:
+                    assert np.array_equal(host(got[k]), want[k]), (k, hp, ap, T, fl)
+                assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"])
+    if spec == (20, 3):  # the default route above 32 768 games: the two-lane kernel takes the small records
+        big = CO.generate_points(40000, m, d, 20, 12)
+        want_p, want = CO.rollout(big, 20, 7)
+        P = dev(big.copy())
+        got = ops.rollout(P, 20, 7, record=fields)
+        assert np.array_equal(host(P), want_p)
+        for k in fields:
+            assert np.array_equal(host(got[k]), want[k]), k
+
+
 @pytest.mark.parametrize("spec", [(20, 3), (10, 3), (4, 3), (8, 4), (20, 4), (50, 4)])
 def test_compiled_rollout_configurations_match_oracle(spec):
     """The two rollout configurations the register-resident kernels carry as compile-time constants (SURVEY
