@@ -23,7 +23,7 @@ dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 # the launches bench.py's headline numbers come from (kernel name pattern, grid size in threads)
-ROLLOUT = (re.compile(r"duo_kernel<20, 3, 1, 1>"), "131072")   # fused rollout, 65 536 games, two lanes per game
+ROLLOUT = (re.compile(r"duo_kernel<20, 3, 1, 1(, false)?>"), "131072")   # fused rollout, 65 536 games, two lanes per game
 STEP = (re.compile(r"quad_kernel<20, 3, 1, \d, 1(, false)?>"), "262144")  # hk_step (JAX-trainer configuration, f32 mask + i32 axis)
 STEP3 = (re.compile(r"quad_kernel<50, 4, 1, \d, 1(, false)?>"), "1048576")  # hk_step at (50,4) x 262 144
 ROLL3 = (re.compile(r"quadroll_kernel<50, 4, 1, 1(, false)?>"), "1048576")  # fused rollout at (50,4) x 262 144
@@ -68,7 +68,7 @@ if trace:
     lines.append("kernel,grid_threads,calls,mean_us,p50_us,p95_us")
     for (k, grid), v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
         v = np.array(v)
-        is_rollout = re.search(r"(fast|duo)_kernel<\d+, \d+, 1, \d>", k) is not None
+        is_rollout = re.search(r"(fast|duo)_kernel<\d+, \d+, 1, \d(, false)?>", k) is not None
         parts = (("T=20 episodes", None), ("T=1 steps", None)) if is_rollout else (("", None),)
         if is_rollout:
             big, small = split_rollout(v)
