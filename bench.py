@@ -70,6 +70,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-step", action="store_true", help="headline only (skip every secondary section)")
     ap.add_argument("--no-search", action="store_true", help="skip config5 (MCTS simulate)")
+    ap.add_argument("--binning", action="store_true",
+                    help="roll the headline episodes out on the batch ordered by live rows (game ids keep the streams)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="skip the two-episodes-in-flight section (profiling runs: its launches overlap in the trace)")
     return ap.parse_args()
@@ -149,6 +151,14 @@ def main():
     stages = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON
     game_offset = rank * b
     fresh = ops.generate_points(b, m, d, MAX_VALUE, seed=42, game_offset=game_offset)
+    # The headline rolls out the GENERATED order.  --binning: the games ordered by live rows at generate time (widest
+    # first, so that a wave holds games of one size), the permutation handed to hk_rollout as game ids -- every game
+    # keeps its policy stream, an episode is game by game the episode of the generated order
+    # (tests/test_gpu_parity.py::test_reordered_batch_with_game_ids_rolls_out_like_the_original).  Not the default:
+    # binning a batch costs more than one episode gains (`binned_by_live_rows` below), it pays for batches that are
+    # rolled out many times or binned off the clock.
+    binned, game_ids = ops.bin_by_live_rows(fresh)
+    head = dict(initial=binned, game_ids=game_ids) if args.binning else dict(initial=fresh)
     state = torch.empty_like(fresh)
     done_count = torch.zeros(EPISODE + 1, dtype=torch.int64, device="cuda")
     step_counts = torch.zeros((EPISODE, 2), dtype=torch.int64, device="cuda")
@@ -223,7 +233,7 @@ def main():
         # episodes back to back, each restarting from the resident fresh states (the kernel reads `fresh`, writes
         # `state`: no copy); the per-workgroup finished-game counts accumulate in `count_ws`
         for _ in range(n_episodes):
-            ops.rollout(state, n_steps, SEED, initial=fresh, defer_counts=True, workspace=count_ws, **kw)
+            ops.rollout(state, n_steps, SEED, defer_counts=True, workspace=count_ws, **head, **kw)
 
     def reduce_counts():
         # ... and are summed into done_count once per BLOCK episodes (the reference sums its per-loop histograms
@@ -333,7 +343,7 @@ def main():
         return r
 
     # ---- the one-launch-per-step variants (rank 0's shard, N=1 only) ----------------------------------------------
-    single = api = dense = legal = large = config3 = config5 = overlapped = None
+    single = api = dense = legal = large = config3 = config5 = overlapped = unbinned = None
     if extras:
         def episode_stepwise():
             for t in range(EPISODE):
@@ -436,6 +446,31 @@ def main():
                           "hk_step_frac_of_hbm_peak": b * bytes_step * EPISODE / smed / 1e9 / HBM_PEAK_GBS}
         done_count.zero_()
 
+        # ---- the same episodes on the batch BINNED by live rows (the round-2 review's proposal: a wave then holds
+        # games of one size), with the permutation as game ids (every game keeps its policy stream) and without -------
+        def binned_episodes(**ids):
+            def run():
+                for _ in range(BLOCK):
+                    ops.rollout(state, EPISODE, SEED, initial=binned, defer_counts=True, workspace=count_ws, **ids, **kw)
+                ops.reduce_counts(count_ws, done_count, b, EPISODE, (m, d))
+            med, _, _ = timed_replays(capture(run).replay, MIN_SECTION_S)
+            return med / BLOCK * 1e6
+        us_ids, us_pos = binned_episodes(game_ids=game_ids), binned_episodes()
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
+        for _ in range(20):
+            ops.bin_by_live_rows(fresh)
+        torch.cuda.synchronize()
+        unbinned = {"us_per_episode_with_game_ids": us_ids, "us_per_episode_positions_as_ids": us_pos,
+                    "binning_us_per_batch": (time.perf_counter() - tb0) / 20 * 1e6,
+                    "note": "secondary, NOT the headline: ops.bin_by_live_rows (hk_get_num_points + a stable sort + a "
+                            "gather; binning_us_per_batch is its host-timed cost) orders the games by live rows, "
+                            "hk_rollout_desc.game_ids keeps every game's policy stream (results identical game by "
+                            "game; the id load delays the action window by ~0.6 us); without ids the binned batch is "
+                            "a batch of its own.  One episode gains less than the binning costs: for batches rolled "
+                            "out many times or binned off the clock"}
+        done_count.zero_()
+
         # ---- two independent episodes in flight (NOT the headline number): the launch of 65 536 games ends with its
         # slowest waves (mean wave lifetime 15 us inside a 21 us kernel, scripts/probe_timeline.py) and nothing
         # backfills the SIMDs that are done; episodes are independent (the reference's compute_rho loops are), so a
@@ -450,9 +485,9 @@ def main():
                 s2.wait_stream(cur)
                 with torch.cuda.stream(s2):
                     for _ in range(BLOCK):
-                        ops.rollout(state_b, EPISODE, SEED + 1, initial=fresh, defer_counts=True, workspace=count_ws_b, **kw)
+                        ops.rollout(state_b, EPISODE, SEED + 1, defer_counts=True, workspace=count_ws_b, **head, **kw)
                 for _ in range(BLOCK):
-                    ops.rollout(state, EPISODE, SEED, initial=fresh, defer_counts=True, workspace=count_ws, **kw)
+                    ops.rollout(state, EPISODE, SEED, defer_counts=True, workspace=count_ws, **head, **kw)
                 cur.wait_stream(s2)
 
             omed, _, _ = timed_replays(capture(two_streams).replay, MIN_SECTION_S)
@@ -619,7 +654,9 @@ def main():
             "config": {
                 "workload": f"dim={d}, max_points={m}, batch={b} games per GPU (BASELINE configs[1]), random "
                             f"host+agent policies sampled in-kernel, reposition=True, rescale=False, episodes of "
-                            f"{EPISODE} steps from generate_pts states (max_value={MAX_VALUE}); fused rollout: "
+                            f"{EPISODE} steps from generate_pts states (max_value={MAX_VALUE}"
+                            + ("; games ordered by live rows at generate time, game ids keep every game's policy stream"
+                               if args.binning else "") + f"); fused rollout: "
                             f"{EPISODE} env steps per launch",
                 "parallelism": f"{world} x independent game shards" + (
                     f"; after EVERY {K}-step region one all-gather of the final states of all ranks "
@@ -638,7 +675,7 @@ def main():
                                   "all-gather (every rank receives all ranks' final states), max over ranks; it is "
                                   "inside `value`")
         for key, val in (("single_step", single), ("boundary_step", api), ("single_step_dense", dense),
-                         ("overlapped_episodes", overlapped), ("large_batch", large),
+                         ("binned_by_live_rows", unbinned), ("overlapped_episodes", overlapped), ("large_batch", large),
                          ("legal_axis_torch_list_semantics", legal),
                          ("config3_dim4_50points", config3), ("config5_mcts_simulate", config5)):
             if val is not None:

@@ -5,7 +5,7 @@ descriptors with host pointers) can import it without a GPU.
 """
 import ctypes as C
 
-HK_ABI_VERSION = 2
+HK_ABI_VERSION = 3
 
 # status codes
 HK_OK = 0
@@ -105,6 +105,7 @@ class hk_rollout_desc(C.Structure):
         ("agent_policy", C.c_int32),
         ("stages", C.c_uint32),
         ("flags", C.c_uint32),
+        ("game_ids", C.c_void_p),
     ]
 
 

@@ -403,6 +403,7 @@ static int params_from_rollout(const hk_rollout_desc* r, Params& prm) {
   prm.game_length_out = r->game_length_out;
   prm.seed = r->seed;
   prm.game_offset = r->game_offset;
+  prm.game_ids = r->game_ids;
   prm.step_offset = r->step_offset;
   prm.steps = r->steps;
   prm.host_policy = r->host_policy;

@@ -86,6 +86,8 @@ struct Params {
   // hk_step_features (four-lane kernel): the observation features of the step's RESULT as a second output
   float* feat_out;     // [batch, m * d] or NULL
   int32_t feat_scale;  // rescale before the sort (scale_observation)
+  // rollouts: the policy stream's game index of position g is game_offset + game_ids[g] (NULL: game_offset + g)
+  const int32_t* game_ids;
 };
 
 // hipGetLastError() is sticky per host thread and other users of the runtime in this process

@@ -477,9 +477,17 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   long long probe_t1 = 0, probe_t2 = 0;
   int probe_steps = 0, probe_smax = 0;
 #endif
+  // (the game id's load goes out BEFORE the slab's: loads return in order, and the action window -- filled while the
+  // slab is in flight -- needs the id; behind the slab requests it would arrive with them: +0.9 us per episode;
+  // the slab requests follow it at once; nothing touches the id before they are out)
+  const bool has_ids = kRoll && prm.game_ids != nullptr;
+  uint32_t raw_id = 0;  // (positions: non-negative; zero-extended below -- a sign extension would wait for the load here)
+  if (has_ids && active) raw_id = (uint32_t)prm.game_ids[g];
+  __builtin_amdgcn_sched_barrier(0);
   DuoSlabRegs<M, D> slab;
   duo_slab_issue<M, D>(slab, in0, in_stride0, g0, ngames, lane);
-  const uint64_t gg = prm.game_offset + (uint64_t)g;
+  __builtin_amdgcn_sched_barrier(0);
+  const uint64_t gg = prm.game_offset + (has_ids ? (uint64_t)raw_id : (uint64_t)g);
   // plain rollouts: the first window of policy words, computed while the slab is in flight
   uint32_t pol_b0 = prm.step_offset >> 2;  // first block of the window (wave-uniform)
   const uint32_t pol_last = (prm.steps > 0) ? (prm.step_offset + (uint32_t)prm.steps - 1u) >> 2 : pol_b0;

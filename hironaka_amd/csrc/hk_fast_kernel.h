@@ -383,9 +383,15 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
   const int ngames = (int)(left < gpb ? left : gpb);
   const bool active = lane < ngames;
   const int64_t g = g0 + lane;
+  // (the game id's load before the slab's, its arithmetic behind them: hk_duo_kernel.h)
+  const bool has_ids = kRoll && prm.game_ids != nullptr;
+  uint32_t raw_id = 0;
+  if (has_ids && active) raw_id = (uint32_t)prm.game_ids[g];
+  __builtin_amdgcn_sched_barrier(0);
   SlabRegs<M, D> slab;
   if (MODE != kModeGenerate) fast_slab_issue<M, D>(slab, in0, in_stride0, g0, ngames, lane);
-  const uint64_t gg = prm.game_offset + (uint64_t)g;
+  __builtin_amdgcn_sched_barrier(0);
+  const uint64_t gg = prm.game_offset + (has_ids ? (uint64_t)raw_id : (uint64_t)g);
   // plain rollouts: the first window of decoded actions, computed while the slab is in flight (Zeillinger's host reads
   // the state: its rollouts keep the policies in the loop and never look at the window)
   uint32_t pol_b0 = prm.step_offset >> 2;  // first Philox block of the window (wave-uniform)

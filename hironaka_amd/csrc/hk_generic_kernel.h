@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kWave) void generic_kernel(const Params prm) {
   }
 
   // ---- kModeRollout: T fused steps, state never leaves LDS ---------------------------------
-  const uint64_t gg = prm.game_offset + (uint64_t)g;
+  const uint64_t gg = prm.game_offset + (uint64_t)((prm.game_ids && active) ? (int64_t)prm.game_ids[g] : g);
   int np = active ? num_points(p, m, d) : 2;
   int length = (np < 2) ? 0 : -1;
   if (prm.count_ws) {

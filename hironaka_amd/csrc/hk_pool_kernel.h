@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kPoolThreads, 2) void pool_kernel(const float* in0,
 // plain rollouts (no per-step records, no Zeillinger host, no sorted output) on a shape with a two-lane kernel
 inline bool pool_supported(const Params& prm) {
   if (prm.mode != kModeRollout || prm.m > 32 || prm.steps > kPoolMaxSteps) return false;
-  if (prm.host_policy == HK_HOST_ZEILLINGER) return false;
+  if (prm.host_policy == HK_HOST_ZEILLINGER || prm.game_ids) return false;
   if (prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out) return false;
   if ((prm.stages & HK_STAGE_NEWTON) &&
       ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)))

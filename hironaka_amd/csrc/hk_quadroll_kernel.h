@@ -590,6 +590,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
 // rollouts (no Zeillinger host, no sorted output) of float32, contiguous, W-aligned records
 inline bool quadroll_request_ok(const Params& prm) {
   if (prm.mode != kModeRollout || prm.m > 255) return false;
+  if (prm.game_ids) return false;  // (re-ordered batches: two-lane / one-lane / generic kernels)
   if (prm.host_policy == HK_HOST_ZEILLINGER) return false;
   if ((prm.stages & HK_STAGE_NEWTON) &&
       ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)))

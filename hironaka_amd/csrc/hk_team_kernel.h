@@ -419,7 +419,8 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
   const bool active = tg < ngames;
   const bool leader = active && tl == 0;
   const int64_t g = g0 + tg;
-  const uint64_t gg = prm.game_offset + (uint64_t)g;
+  const uint64_t gg =
+      prm.game_offset + (uint64_t)((prm.mode == kModeRollout && prm.game_ids && active) ? (int64_t)prm.game_ids[g] : g);
   float* mine = lds + tg * S;
   const float pad = (float)prm.pad;
   const unsigned flags = prm.flags;

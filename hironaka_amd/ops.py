@@ -425,7 +425,8 @@ def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0
             padding_value: float = -1.0, reward_sign: float = 1.0, record: Sequence[str] = (),
             done_count: Optional[torch.Tensor] = None,
             initial: Optional[torch.Tensor] = None, defer_counts: bool = False,
-            workspace: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+            workspace: Optional[torch.Tensor] = None,
+            game_ids: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """T fused steps with in-kernel policies (hk_rollout); `points` is updated IN PLACE.
     record: any of "obs", "host_class", "axis", "done", "reward", "game_length".
     done_count: optional uint64-as-int64 [steps+1] accumulator (zeroed by the caller).
@@ -433,7 +434,9 @@ def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0
         `points` only receives the final state (an episode restart without a device copy).
     defer_counts: leave the finished-game counts as partial sums in `workspace` (from `rollout_workspace`;
         they accumulate over launches) and skip the reduce kernel; `reduce_counts` adds them to a
-        done_count later -- one reduction for many rollouts."""
+        done_count later -- one reduction for many rollouts.
+    game_ids: optional int32 [B]: the policy stream of the game at position g is keyed by game_offset + game_ids[g]
+        (a batch re-ordered by `bin_by_live_rows` rolls out game by game as the original order would)."""
     _require_device(points, "points")
     if points.dtype not in (torch.float32, torch.float64) or not points.is_contiguous() or points.dim() != 3:
         raise ValueError("rollout updates a contiguous [B, m, d] float32/float64 tensor in place")
@@ -445,6 +448,11 @@ def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0
                 or initial.device != dev):
             raise ValueError("initial must match points in shape, dtype, device and be contiguous")
     r = A.hk_rollout_desc()
+    if game_ids is not None:
+        _require_device(game_ids, "game_ids")
+        if game_ids.dtype != torch.int32 or game_ids.shape != (b,) or not game_ids.is_contiguous() or game_ids.device != dev:
+            raise ValueError("game_ids must be a contiguous int32 [B] tensor on the device of points")
+        r.game_ids = game_ids.data_ptr()
     res: Dict[str, torch.Tensor] = {}
     if defer_counts:
         if workspace is None:
@@ -486,6 +494,20 @@ def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0
         check(lib().hk_rollout(C.byref(r), _stream(points)), "hk_rollout")
     res["points"] = points
     return res
+
+
+def bin_by_live_rows(points: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Games re-ordered by their number of live rows, widest first (stable), and the permutation as int32 `game_ids`
+    (position -> original index) for `rollout(..., game_ids=)`: a wave of the rollout kernels then holds games of one
+    size -- its slots per lane are the widest game's -- and every game keeps its policy stream, so the re-ordered batch
+    rolls out exactly as the original one, game by game.  Done once, where the batch is generated (the reference's
+    batches carry no order: jax/util.py:385-392 draws them at random); the sort itself is tensor-library plumbing
+    around hk_get_num_points."""
+    _require_device(points, "points")
+    if points.dim() != 3:
+        raise ValueError("points must be [B, m, d]")
+    order = torch.argsort(get_num_points(points), descending=True, stable=True)
+    return points.index_select(0, order).contiguous(), order.to(torch.int32)
 
 
 def has_fast_path(max_points: int, dim: int, dtype=torch.float32) -> bool:

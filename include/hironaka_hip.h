@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define HK_ABI_VERSION 2 /* 2: + HK_AXIS_MASKED_LOGITS, hk_step_features, hk_rollout_values, hk_search_expand_* / _masked_argmax / _mask_logits */
+#define HK_ABI_VERSION 3 /* 2: + HK_AXIS_MASKED_LOGITS, hk_step_features, hk_rollout_values, hk_search_expand_* / _masked_argmax / _mask_logits; 3: + hk_rollout_desc.game_ids */
 
 /* ---- status codes -------------------------------------------------------------------- */
 #define HK_OK 0
@@ -202,6 +202,12 @@ typedef struct hk_rollout_desc {
   int32_t agent_policy;
   uint32_t stages;
   uint32_t flags;
+  const int32_t* game_ids; /* [batch] or NULL: the policy stream of the game at position g is keyed
+                              by game_offset + game_ids[g] instead of game_offset + g -- a batch
+                              whose games were re-ordered (binned by live rows at generate time so
+                              that a wave holds games of one size) rolls out exactly as the
+                              original order would, game by game.  The reference's batches carry
+                              no order (jax/util.py:385-392 draws them at random).              */
 } hk_rollout_desc;
 
 /* ---- library ---------------------------------------------------------------------------- */

@@ -217,10 +217,14 @@ def generate_points(batch, max_points, dim, max_value, seed, game_offset=0, dtyp
 def rollout(points: np.ndarray, steps: int, seed: int, *, game_offset=0, step_offset=0,
             host_policy=A.HK_HOST_RANDOM, agent_policy=A.HK_AGENT_RANDOM,
             stages=A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON, flags=0,
-            padding_value=-1.0, reward_sign=1.0, record=True):
+            padding_value=-1.0, reward_sign=1.0, record=True, game_ids=None):
     p = np.array(points, copy=True, order="C")
     b, m, d = p.shape
     r = A.hk_rollout_desc()
+    if game_ids is not None:
+        ids = np.ascontiguousarray(game_ids, dtype=np.int32)
+        assert ids.shape == (b,)
+        r.game_ids = _ptr(ids)
     counts = np.zeros(steps + 1, dtype=np.uint64)
     rec = dict(done_count=counts, game_length=np.empty(b, dtype=np.int32))
     r.points, r.done_count, r.game_length_out = _ptr(p), _ptr(counts), _ptr(rec["game_length"])

@@ -456,6 +456,43 @@ def test_small_records_without_observations_match_oracle(spec):
             assert np.array_equal(host(got[k]), want[k]), k
 
 
+@pytest.mark.parametrize("spec", [(20, 3), (8, 4), (50, 4), (7, 3)])
+def test_reordered_batch_with_game_ids_rolls_out_like_the_original(spec):
+    """`hk_rollout_desc.game_ids` (round 3): a batch binned by live rows (`ops.bin_by_live_rows`) with the permutation as
+    game ids gives, game by game, what the original order gives -- against the oracle with the same ids, and as the
+    permutation of the plain run; every family that serves re-ordered batches (two lanes, one lane, team, generic; the
+    four-lane and pool kernels step aside), records included."""
+    m, d = spec
+    p0 = CO.generate_points(32 * 9 + 5, m, d, 20, 21)
+    P0 = dev(p0.copy())
+    binned, ids = ops.bin_by_live_rows(P0)
+    idn = host(ids)
+    assert sorted(idn.tolist()) == list(range(p0.shape[0]))
+    cnt = (p0[:, :, 0] >= 0).sum(1)
+    assert np.array_equal(host(binned), p0[idn]) and np.all(np.diff(cnt[idn]) <= 0)
+    fields = ("host_class", "axis", "done", "reward", "game_length")
+    for hp, ap in ((A.HK_HOST_RANDOM, A.HK_AGENT_RANDOM), (A.HK_HOST_RANDOM, A.HK_AGENT_RANDOM_LEGAL),
+                   (A.HK_HOST_ZEILLINGER, A.HK_AGENT_CHOOSE_FIRST)):
+        for T, so in ((20, 0), (30, 6)):
+            plain_p, plain = CO.rollout(p0, T, 5, game_offset=100, step_offset=so, host_policy=hp, agent_policy=ap)
+            want_p, want = CO.rollout(p0[idn], T, 5, game_offset=100, step_offset=so, host_policy=hp, agent_policy=ap,
+                                      game_ids=idn)
+            # the oracle itself: the re-ordered run is the permutation of the plain one
+            assert np.array_equal(want_p, plain_p[idn]) and np.array_equal(want["game_length"], plain["game_length"][idn])
+            assert np.array_equal(want["done_count"], plain["done_count"])
+            for fl in (0, A.HK_FLAG_FORCE_TWO_LANES, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC):
+                if fl == A.HK_FLAG_FORCE_TWO_LANES and (m > 32 or hp == A.HK_HOST_ZEILLINGER):
+                    continue
+                for rec in (fields, ("obs",) + fields, ("game_length",)):
+                    Q = binned.clone()
+                    got = ops.rollout(Q, T, 5, game_offset=100, step_offset=so, host_policy=hp, agent_policy=ap, flags=fl,
+                                      record=rec, game_ids=ids)
+                    assert np.array_equal(host(Q), want_p), (hp, ap, T, fl, rec)
+                    for k in rec:
+                        assert np.array_equal(host(got[k]), want[k]), (k, hp, ap, T, fl)
+                    assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"])
+
+
 @pytest.mark.parametrize("spec", [(20, 3), (10, 3), (4, 3), (8, 4), (20, 4), (50, 4)])
 def test_compiled_rollout_configurations_match_oracle(spec):
     """The two rollout configurations the register-resident kernels carry as compile-time constants (SURVEY

@@ -431,6 +431,21 @@ def test_rollout_sharding_invariance():
     assert rf["done_count"][-1] == rf["done"][-1].sum()
 
 
+def test_rollout_game_ids_permutation_invariance():
+    """hk_rollout_desc.game_ids (ABI 3): a re-ordered batch with the permutation as game ids is, game by game, the
+    run of the original order -- records, lengths and counts (the contract `ops.bin_by_live_rows` relies on)."""
+    p0 = CO.generate_points(97, 20, 3, 20, 4)
+    perm = np.argsort(-(p0[:, :, 0] >= 0).sum(1), kind="stable").astype(np.int32)
+    for hp, ap in ((A.HK_HOST_RANDOM, A.HK_AGENT_RANDOM), (A.HK_HOST_ZEILLINGER, A.HK_AGENT_RANDOM_LEGAL)):
+        pf, rf = CO.rollout(p0, 26, 3, game_offset=1 << 33, step_offset=2, host_policy=hp, agent_policy=ap)
+        pb, rb = CO.rollout(p0[perm], 26, 3, game_offset=1 << 33, step_offset=2, host_policy=hp, agent_policy=ap,
+                            game_ids=perm)
+        assert np.array_equal(pb, pf[perm]) and np.array_equal(rb["game_length"], rf["game_length"][perm])
+        for k in ("obs", "host_class", "axis", "done", "reward"):
+            assert np.array_equal(rb[k], rf[k][:, perm]), k
+        assert np.array_equal(rb["done_count"], rf["done_count"])
+
+
 def test_philox_known_answer():
     """Philox4x32-10 known-answer vectors from the Random123 distribution (kat_vectors):
     counter = key = 0 and the pi-digits vector."""
