@@ -72,6 +72,8 @@ def parse_args():
     ap.add_argument("--no-search", action="store_true", help="skip config5 (MCTS simulate)")
     ap.add_argument("--binning", action="store_true",
                     help="roll the headline episodes out on the batch ordered by live rows (game ids keep the streams)")
+    ap.add_argument("--no-binned", action="store_true",
+                    help="skip the binned_by_live_rows section (profile passes: its launches share the headline kernel's name)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="skip the two-episodes-in-flight section (profiling runs: its launches overlap in the trace)")
     return ap.parse_args()
@@ -449,6 +451,9 @@ def main():
         # ---- the same episodes on the batch BINNED by live rows (the round-2 review's proposal: a wave then holds
         # games of one size), with the permutation as game ids (every game keeps its policy stream) and without -------
         def binned_episodes(**ids):
+            if args.no_binned:
+                return None
+
             def run():
                 for _ in range(BLOCK):
                     ops.rollout(state, EPISODE, SEED, initial=binned, defer_counts=True, workspace=count_ws, **ids, **kw)
@@ -461,7 +466,7 @@ def main():
         for _ in range(20):
             ops.bin_by_live_rows(fresh)
         torch.cuda.synchronize()
-        unbinned = {"us_per_episode_with_game_ids": us_ids, "us_per_episode_positions_as_ids": us_pos,
+        unbinned = None if args.no_binned else {"us_per_episode_with_game_ids": us_ids, "us_per_episode_positions_as_ids": us_pos,
                     "binning_us_per_batch": (time.perf_counter() - tb0) / 20 * 1e6,
                     "note": "secondary, NOT the headline: ops.bin_by_live_rows (hk_get_num_points + a stable sort + a "
                             "gather; binning_us_per_batch is its host-timed cost) orders the games by live rows, "
