@@ -651,7 +651,12 @@ inline bool quadroll_default(const Params& prm, int simds, bool small_records_el
   if (prm.m > 32) return true;
   if (prm.obs_out) return true;
   if ((prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out) && !small_records_elsewhere) return true;
-  return ((int64_t)prm.batch + kQuadGames - 1) / kQuadGames <= (int64_t)2 * simds;
+  const int64_t waves = ((int64_t)prm.batch + kQuadGames - 1) / kQuadGames;
+  // short rollouts (measured at (20,3) x 65 536, scripts/probe_short_rollouts.py: 1 / 2 / 4 / 6 steps 8.2 / 10.0 / 12.3 /
+  // 14.4 us against the two-lane kernel's 9.6 / 11.5 / 13.6 / 15.0; level at 8 steps): the wave's shorter chain
+  // counts while the wide first steps are most of the launch
+  if (prm.steps <= 6 && waves <= (int64_t)4 * simds) return true;
+  return waves <= (int64_t)2 * simds;
 }
 
 // workgroups of a launch (the finished-game workspace has one slot per workgroup and step)
