@@ -402,6 +402,157 @@ __device__ inline void duo_policy_words(uint64_t gg, uint32_t step, uint64_t see
   agent_word = w << 16;
 }
 
+// ---- Zeillinger's host on the pair's rows (jax/players.py:55-109; hk_fast_rows.h: c_zeillinger is the one-lane twin) --
+// Over the pairs i < j of live rows (row-major order = rank order: the deals keep it): the characteristic vector
+// (L, S) = (max - min, #max + #min) of P_i - P_j, differences that are constant (jnp.isclose) do not count, the first
+// minimum wins, the subset is {argmin, argmax} of that difference; no pair: class 0.  Rank of (slot s, lane h) = 2 s + h.
+// A lane takes its own slots a < b and, against the partner's rows (DPP), the slots b >= a (lane 1: b > a) -- every
+// pair once, "mine" always the earlier row: NB^2 tests per lane where the one-lane kernel runs 2 NB^2 on half the
+// waves.  "First" is explicit -- the pair's index 64 i + j breaks ties --, so the two lanes' bests merge by the same
+// comparison.
+// Buckets of more than kDuoZeilDpp slots per lane: the same pairs as a ROLLED loop over the game's rows parked by
+// rank in its image (scratch between two deals) -- unrolled, 64 pair tests on 8 slots per lane spilled 692 B per lane
+// and a first step took 51 us; lane h takes the rows i = h, h + 2, ... against every later row.
+constexpr int kDuoZeilDpp = 4;
+
+// The best pair so far as ONE comparable key: hi = the bits of L (a non-negative finite float: its bit pattern orders
+// like its value), lo = S << 16 | 64 i + j -- "smaller (L, S), then the earlier pair" is an unsigned compare of (hi, lo).
+template <int D>
+struct DuoZeilBest {
+  uint32_t hi = 0xFFFFFFFFu, lo = 0xFFFFFFFFu;  // (all ones: none yet)
+  float bd[D];                                  // the pair's difference (KEEP; else re-read from the parked rows)
+};
+
+// one pair (mine = the earlier row i, other = row j): its characteristic vector against the best so far.  ~25
+// instructions: max / min / median of three are single instructions, #max + #min = 2 + (median == max) + (median == min)
+// in dimension 3; every term is bitwise (with && / || the compiler made each one a branch on the exec mask: 14 per pair)
+template <int D, bool KEEP>
+__device__ __forceinline__ void duo_zeil_pair(DuoZeilBest<D>& best, const float* mine, const float* other, bool ok, int idx) {
+  float v[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) v[k] = mine[k] - other[k];
+  float mx, mn;
+  uint32_t cnt;
+  if constexpr (D == 3) {
+    mx = __builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]);
+    mn = __builtin_fminf(__builtin_fminf(v[0], v[1]), v[2]);
+    const float md = __builtin_amdgcn_fmed3f(v[0], v[1], v[2]);
+    cnt = 2u + (uint32_t)(md == mx) + (uint32_t)(md == mn);
+  } else {
+    mx = v[0];
+    mn = v[0];
+#pragma unroll
+    for (int k = 1; k < D; ++k) {
+      mx = __builtin_fmaxf(mx, v[k]);
+      mn = __builtin_fminf(mn, v[k]);
+    }
+    cnt = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) cnt += (uint32_t)(v[k] == mx) + (uint32_t)(v[k] == mn);
+  }
+  const float L = mx - mn;
+  const bool close = fabsf(L) <= 1e-8f + 1e-5f * fabsf(mn);  // jnp.isclose(max, min)
+  const bool valid = ok & (mine[0] < INFINITY) & (other[0] < INFINITY) & !close;
+  const uint32_t khi = __float_as_uint(L), klo = (cnt << 16) | (uint32_t)idx;
+  const bool better = valid & ((khi < best.hi) | ((khi == best.hi) & (klo < best.lo)));
+  best.hi = better ? khi : best.hi;
+  best.lo = better ? klo : best.lo;
+  if constexpr (KEEP) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) best.bd[k] = better ? v[k] : best.bd[k];
+  }
+}
+
+template <int D, bool KEEP>
+__device__ __forceinline__ void duo_zeil_merge(DuoZeilBest<D>& best, const DuoZeilBest<D>& o) {
+  const bool take = (o.hi < best.hi) | ((o.hi == best.hi) & (o.lo < best.lo));
+  best.hi = take ? o.hi : best.hi;
+  best.lo = take ? o.lo : best.lo;
+  if constexpr (KEEP) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) best.bd[k] = take ? o.bd[k] : best.bd[k];
+  }
+}
+
+template <int CH, int D, int NB>
+__device__ __forceinline__ int duo_zeillinger(const float (&q)[CH * D], int h, float* mine, int smax) {
+  constexpr bool KEEP = NB <= kDuoZeilDpp;
+  DuoZeilBest<D> best;
+#pragma unroll
+  for (int k = 0; k < D; ++k) best.bd[k] = 0.0f;
+  if constexpr (KEEP) {
+    float p[NB * D];
+#pragma unroll
+    for (int e = 0; e < NB * D; ++e) p[e] = duo_other(q[e]);
+#pragma unroll
+    for (int a = 0; a < NB; ++a) {
+#pragma unroll
+      for (int b = a + 1; b < NB; ++b)
+        duo_zeil_pair<D, true>(best, &q[a * D], &q[b * D], true, (128 * a + 2 * b) + 65 * h);
+#pragma unroll
+      for (int b = a; b < NB; ++b)
+        duo_zeil_pair<D, true>(best, &q[a * D], &p[b * D], (b > a) | (h == 0), (128 * a + 2 * b + 1) + 63 * h);
+      if constexpr (NB > 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    __syncthreads();  // (a workgroup is one wave)
+#pragma unroll
+    for (int s = 0; s < NB; ++s)
+#pragma unroll
+      for (int k = 0; k < D; ++k) mine[(2 * s + h) * D + k] = q[s * D + k];
+    __syncthreads();
+    const int n = 2 * smax;  // ranks in use (wave-uniform); holes are +inf
+    // two pairs per pass with a best of their own each (two independent chains; the order of the merges does not
+    // matter: the pair index is part of the key)
+    DuoZeilBest<D> second;
+#pragma nounroll
+    for (int i = h; i + 1 < n; i += 2) {
+      float pi[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) pi[k] = mine[i * D + k];
+#pragma nounroll
+      for (int j = i + 1; j < n; j += 2) {
+        float pj[D], pk[D];
+        const int j2 = (j + 1 < n) ? j + 1 : j;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          pj[k] = mine[j * D + k];
+          pk[k] = mine[j2 * D + k];
+        }
+        duo_zeil_pair<D, false>(best, pi, pj, true, 64 * i + j);
+        duo_zeil_pair<D, false>(second, pi, pk, j + 1 < n, 64 * i + j + 1);
+      }
+    }
+    duo_zeil_merge<D, false>(best, second);
+  }
+  {  // the partner's best
+    DuoZeilBest<D> o;
+    o.hi = (uint32_t)duo_other_i((int)best.hi);
+    o.lo = (uint32_t)duo_other_i((int)best.lo);
+    if constexpr (KEEP) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) o.bd[k] = duo_other(best.bd[k]);
+    }
+    duo_zeil_merge<D, KEEP>(best, o);
+  }
+  const bool have = best.hi != 0xFFFFFFFFu;
+  if constexpr (!KEEP) {  // the chosen pair's difference from the parked rows
+    const int i = have ? (int)((best.lo & 0xFFFFu) >> 6) : 0, j = have ? (int)(best.lo & 63u) : 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) best.bd[k] = mine[i * D + k] - mine[j * D + k];
+    __syncthreads();  // (the image is written again by the next deal)
+  }
+  int lo = 0, hi = 0;
+  float vlo = best.bd[0], vhi = best.bd[0];
+#pragma unroll
+  for (int k = 1; k < D; ++k) {
+    if (best.bd[k] < vlo) { vlo = best.bd[k]; lo = k; }
+    if (best.bd[k] > vhi) { vhi = best.bd[k]; hi = k; }
+  }
+  if (!have || lo == hi) return 0;
+  return encode_mask((1u << lo) | (1u << hi));
+}
+
 // ---- the policy stream off the critical path (plain rollouts) ------------------------------------------------------
 // A Philox block is ~115 instructions, 20 of them quarter-rate 32 x 32 -> 64 multiplies in a dependent chain of ten
 // rounds: computed inside the step loop (one block per lane every four steps) it was a fifth of the loop's
@@ -449,10 +600,13 @@ __device__ __forceinline__ void duo_policy_fill(uint8_t* act, uint64_t gg, uint3
 // single steps with the caller's actions (kModeStep: hk_step) -------------------------------------------------
 // ACTS (plain rollouts): the kernel also writes the small per-step records (flush_records below) -- its own
 // instantiation, the headline kernel carries none of it (measured: +0.4 us per 65 536-game episode as a run-time branch)
-template <int M, int D, int MODE, int HOT = kHotNone, bool ACTS = false>
+// ZEIL (plain rollouts): Zeillinger's host -- its choice depends on the state, so the policies stay inside the loop
+// (duo_zeillinger on the rows in registers + the pair's Philox words), no action window; its own instantiation too.
+template <int M, int D, int MODE, int HOT = kHotNone, bool ACTS = false, bool ZEIL = false>
 __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t in_stride0, int batch0,
                                                        const Params prm) {
   static_assert(!ACTS || MODE == kModeRollout, "the small records ride on the plain rollout");
+  static_assert(!ZEIL || (MODE == kModeRollout && HOT == kHotNone && !ACTS), "Zeillinger's host: plain rollouts");
   constexpr bool kRec = MODE == kModeRolloutRec;
   constexpr bool kRoll = MODE == kModeRollout || kRec;
   using G = FastGeom<M, D>;
@@ -491,7 +645,7 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   // plain rollouts: the first window of policy words, computed while the slab is in flight
   uint32_t pol_b0 = prm.step_offset >> 2;  // first block of the window (wave-uniform)
   const uint32_t pol_last = (prm.steps > 0) ? (prm.step_offset + (uint32_t)prm.steps - 1u) >> 2 : pol_b0;
-  if constexpr (MODE == kModeRollout) {
+  if constexpr (MODE == kModeRollout && !ZEIL) {
     const uint32_t nb = pol_last - pol_b0 + 1u;
     duo_policy_fill<D>(pol, gg, pol_b0, (int)(nb < (uint32_t)kDuoPreBlocks ? nb : (uint32_t)kDuoPreBlocks), prm.seed,
                        HOT ? (int)HK_HOST_RANDOM : prm.host_policy,
@@ -679,7 +833,7 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
     int t = 0;
     bool stop = false;
     while (t < nsteps && !stop) {  // one pass per window of policy words (episodes of up to 24 steps: one pass)
-    if ((uint32_t)((step0 + (uint32_t)t) >> 2) - pol_b0 >= (uint32_t)kDuoPreBlocks) {
+    if (!ZEIL && (uint32_t)((step0 + (uint32_t)t) >> 2) - pol_b0 >= (uint32_t)kDuoPreBlocks) {
       if constexpr (want_small) flush_records(__builtin_amdgcn_readfirstlane(t));
       __syncthreads();
       pol_b0 = (step0 + (uint32_t)t) >> 2;
@@ -690,7 +844,7 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
     }
     // last step (exclusive) the window covers
     const uint32_t wend_abs = (pol_b0 + (uint32_t)kDuoPreBlocks) << 2;
-    const int tw = (wend_abs - step0 < (uint32_t)nsteps) ? (int)(wend_abs - step0) : nsteps;
+    const int tw = (!ZEIL && wend_abs - step0 < (uint32_t)nsteps) ? (int)(wend_abs - step0) : nsteps;
     DuoLevels<CH>::run([&](auto nbc, auto loc) {
       constexpr int NB = decltype(nbc)::value, LO = decltype(loc)::value;
 #ifndef HK_NO_SETPRIO
@@ -711,9 +865,19 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
           if (t == 10) __builtin_amdgcn_s_setprio(3);
         }
 #endif
-        const uint32_t a = pol[(int)(step0 + (uint32_t)t - (pol_b0 << 2)) * kDuoGames + gi];
-        const uint32_t mask = a & 31u;
-        const int axis = (int)(a >> 5);
+        uint32_t mask;
+        int axis;
+        if constexpr (ZEIL) {
+          const int zc = duo_zeillinger<CH, D, NB>(q, h, mine, smax);
+          uint32_t ra, rb;
+          int cls;
+          duo_policy_words(gg, step0 + (uint32_t)t, seed, dcache, h, ra, rb);
+          policy_from_words<D>(ra, rb, host_policy, agent_policy, cls, axis, mask, zc);
+        } else {
+          const uint32_t a = pol[(int)(step0 + (uint32_t)t - (pol_b0 << 2)) * kDuoGames + gi];
+          mask = a & 31u;
+          axis = (int)(a >> 5);
+        }
         const unsigned st = (end_sort && t + 1 == nsteps) ? (stages & ~(unsigned)HK_STAGE_RESCALE) : stages;
         rescale_pending = end_sort && t + 1 == nsteps && (stages & HK_STAGE_RESCALE);
         np = d_stages<CH, D, NB, true>(q, c, axis, np, h, flags, st, mask);
@@ -897,7 +1061,9 @@ inline int device_simds() {
 inline bool duo_wanted(const Params& prm) {
   if ((prm.mode != kModeRollout && prm.mode != kModeStep) || prm.m > 32) return false;
   if (prm.mode == kModeStep && (prm.class_out || (prm.stages & kStageFeatureSorts))) return false;
-  if (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER) return false;
+  const bool any_records = prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out;
+  // Zeillinger's host: plain rollouts (duo_kernel<..., ZEIL>); with records the one-lane kernel
+  if (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER && any_records) return false;
   if ((prm.stages & HK_STAGE_NEWTON) &&
       ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED))) {
     // sorted + compacted output: plain rollouts only (they sort once, at the end)
@@ -923,6 +1089,9 @@ int launch_duo_t(Params prm, hipStream_t stream) {
   if (prm.mode == kModeRollout && records)
     hipLaunchKernelGGL((duo_kernel<M, D, kModeRolloutRec>), dim3(grid), dim3(kWave), 0, stream, (const float*)prm.in,
                        prm.in_stride, prm.batch, prm);
+  else if (prm.mode == kModeRollout && prm.host_policy == HK_HOST_ZEILLINGER)
+    hipLaunchKernelGGL((duo_kernel<M, D, kModeRollout, kHotNone, false, true>), dim3(grid), dim3(kWave), 0, stream,
+                       (const float*)prm.in, prm.in_stride, prm.batch, prm);
   else if (prm.mode == kModeRollout && acts && hot == kHotJax)
     hipLaunchKernelGGL((duo_kernel<M, D, kModeRollout, kHotJax, true>), dim3(grid), dim3(kWave), 0, stream,
                        (const float*)prm.in, prm.in_stride, prm.batch, prm);

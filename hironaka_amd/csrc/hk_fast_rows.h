@@ -511,8 +511,9 @@ __device__ __forceinline__ int c_zeillinger(const float (&q)[C * D], int nmax, b
 #pragma unroll
       for (int k = 0; k < D; ++k) cnt += (float)((v[k] == mx) + (v[k] == mn));
       const float L = mx - mn;
-      const bool valid = live_i && (q[j * D] < INFINITY) && (LIST || !close);
-      const bool better = valid && ((LIST && !have) || L < bestL || (L == bestL && cnt < bestS));
+      // (bitwise on purpose: && / || become branches on the exec mask, one per term and pair)
+      const bool valid = live_i & (q[j * D] < INFINITY) & (LIST | !close);
+      const bool better = valid & ((LIST & !have) | (L < bestL) | ((L == bestL) & (cnt < bestS)));
       bestL = better ? L : bestL;
       bestS = better ? cnt : bestS;
 #pragma unroll

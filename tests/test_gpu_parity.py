@@ -456,6 +456,33 @@ def test_small_records_without_observations_match_oracle(spec):
             assert np.array_equal(host(got[k]), want[k]), k
 
 
+@pytest.mark.parametrize("spec", [(20, 3), (10, 3), (4, 3), (5, 3), (16, 3), (8, 4), (20, 4)])
+def test_zeillinger_host_plain_rollouts_match_oracle(spec):
+    """Plain rollouts against Zeillinger's host (jax/players.py:55-109) on the two-lane kernel (`duo_kernel<..., ZEIL>`:
+    the pair test split over the two lanes of a game, ties by the explicit pair index) and on the one-lane kernel,
+    against the oracle: wide states (every bucket of the staircase), states of small integers (many equal
+    characteristic vectors: the first pair in row-major order must win), ragged waves, a step offset inside a Philox
+    block, one game off the exact path."""
+    m, d = spec
+    for max_value, seed in ((20, 31), (3, 32), (2, 33)):
+        p0 = CO.generate_points(32 * 6 + 9, m, d, max_value, seed)
+        if max_value == 20:
+            dense = CO.generate_points(64, m, d, 20, 34, stages=0)  # every row live: the widest buckets
+            p0 = np.concatenate([p0, dense])
+            p0[70, 1, 0] = -1.0  # partly padded row: whole-wave slow path
+        for ap in (A.HK_AGENT_RANDOM, A.HK_AGENT_RANDOM_LEGAL, A.HK_AGENT_CHOOSE_FIRST):
+            for T, so in ((20, 0), (11, 6)):
+                want_p, want = CO.rollout(p0, T, 13, game_offset=9, step_offset=so, host_policy=A.HK_HOST_ZEILLINGER,
+                                          agent_policy=ap, record=False)
+                for fl in (0, A.HK_FLAG_FORCE_TWO_LANES, A.HK_FLAG_FORCE_ONE_LANE):
+                    P = dev(p0.copy())
+                    got = ops.rollout(P, T, 13, game_offset=9, step_offset=so, host_policy=A.HK_HOST_ZEILLINGER,
+                                      agent_policy=ap, flags=fl, record=("game_length",))
+                    assert np.array_equal(host(P), want_p), (max_value, ap, T, fl)
+                    assert np.array_equal(host(got["game_length"]), want["game_length"]), (max_value, ap, T, fl)
+                    assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"])
+
+
 @pytest.mark.parametrize("spec", [(20, 3), (8, 4), (50, 4), (7, 3)])
 def test_reordered_batch_with_game_ids_rolls_out_like_the_original(spec):
     """`hk_rollout_desc.game_ids` (round 3): a batch binned by live rows (`ops.bin_by_live_rows`) with the permutation as
