@@ -448,6 +448,20 @@ def main():
                           "hk_step_frac_of_hbm_peak": b * bytes_step * EPISODE / smed / 1e9 / HBM_PEAK_GBS}
         done_count.zero_()
 
+        # ---- the reference's benchmark opponent: Zeillinger's host (jax/players.py:55-109; SURVEY f-4) against the
+        # random agent on the host's subset -- its choice reads the state, so the policies run inside the step loop
+        def roll_zeillinger():
+            for _ in range(BLOCK):
+                ops.rollout(state, EPISODE, SEED, initial=fresh, stages=stages, defer_counts=True, workspace=count_ws,
+                            host_policy=A.HK_HOST_ZEILLINGER, agent_policy=A.HK_AGENT_RANDOM_LEGAL)
+            ops.reduce_counts(count_ws, done_count, b, EPISODE, (m, d))
+
+        zmed, _, _ = timed_replays(capture(roll_zeillinger).replay, MIN_SECTION_S)
+        legal["zeillinger_host"] = {"fused_rollout_us_per_episode": zmed / BLOCK * 1e6,
+                                    "fused_env_steps_per_s": b * EPISODE * BLOCK / zmed,
+                                    "note": "two lanes per game, the pair test split over them (duo_kernel<..., ZEIL>)"}
+        done_count.zero_()
+
         # ---- the same episodes on the batch BINNED by live rows (the round-2 review's proposal: a wave then holds
         # games of one size), with the permutation as game ids (every game keeps its policy stream) and without -------
         def binned_episodes(**ids):

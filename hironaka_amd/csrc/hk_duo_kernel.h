@@ -416,69 +416,10 @@ __device__ inline void duo_policy_words(uint64_t gg, uint32_t step, uint64_t see
 // 20-step episode of 65 536 games: DPP up to 4 slots 47.5 us, up to 6 slots 44.3 us; 242 VGPRs, no scratch.)
 constexpr int kDuoZeilDpp = 6;
 
-// The best pair so far as ONE comparable key: hi = the bits of L (a non-negative finite float: its bit pattern orders
-// like its value), lo = S << 16 | 64 i + j -- "smaller (L, S), then the earlier pair" is an unsigned compare of (hi, lo).
-template <int D>
-struct DuoZeilBest {
-  uint32_t hi = 0xFFFFFFFFu, lo = 0xFFFFFFFFu;  // (all ones: none yet)
-  float bd[D];                                  // the pair's difference (KEEP; else re-read from the parked rows)
-};
-
-// one pair (mine = the earlier row i, other = row j): its characteristic vector against the best so far.  ~25
-// instructions: max / min / median of three are single instructions, #max + #min = 2 + (median == max) + (median == min)
-// in dimension 3; every term is bitwise (with && / || the compiler made each one a branch on the exec mask: 14 per pair)
-template <int D, bool KEEP>
-__device__ __forceinline__ void duo_zeil_pair(DuoZeilBest<D>& best, const float* mine, const float* other, bool ok, int idx) {
-  float v[D];
-#pragma unroll
-  for (int k = 0; k < D; ++k) v[k] = mine[k] - other[k];
-  float mx, mn;
-  uint32_t cnt;
-  if constexpr (D == 3) {
-    mx = __builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]);
-    mn = __builtin_fminf(__builtin_fminf(v[0], v[1]), v[2]);
-    const float md = __builtin_amdgcn_fmed3f(v[0], v[1], v[2]);
-    cnt = 2u + (uint32_t)(md == mx) + (uint32_t)(md == mn);
-  } else {
-    mx = v[0];
-    mn = v[0];
-#pragma unroll
-    for (int k = 1; k < D; ++k) {
-      mx = __builtin_fmaxf(mx, v[k]);
-      mn = __builtin_fminf(mn, v[k]);
-    }
-    cnt = 0;
-#pragma unroll
-    for (int k = 0; k < D; ++k) cnt += (uint32_t)(v[k] == mx) + (uint32_t)(v[k] == mn);
-  }
-  const float L = mx - mn;
-  const bool close = fabsf(L) <= 1e-8f + 1e-5f * fabsf(mn);  // jnp.isclose(max, min)
-  const bool valid = ok & (mine[0] < INFINITY) & (other[0] < INFINITY) & !close;
-  const uint32_t khi = __float_as_uint(L), klo = (cnt << 16) | (uint32_t)idx;
-  const bool better = valid & ((khi < best.hi) | ((khi == best.hi) & (klo < best.lo)));
-  best.hi = better ? khi : best.hi;
-  best.lo = better ? klo : best.lo;
-  if constexpr (KEEP) {
-#pragma unroll
-    for (int k = 0; k < D; ++k) best.bd[k] = better ? v[k] : best.bd[k];
-  }
-}
-
-template <int D, bool KEEP>
-__device__ __forceinline__ void duo_zeil_merge(DuoZeilBest<D>& best, const DuoZeilBest<D>& o) {
-  const bool take = (o.hi < best.hi) | ((o.hi == best.hi) & (o.lo < best.lo));
-  best.hi = take ? o.hi : best.hi;
-  best.lo = take ? o.lo : best.lo;
-  if constexpr (KEEP) {
-#pragma unroll
-    for (int k = 0; k < D; ++k) best.bd[k] = take ? o.bd[k] : best.bd[k];
-  }
-}
-
 template <int CH, int D, int NB>
 __device__ __forceinline__ int duo_zeillinger(const float (&q)[CH * D], int h, float* mine, int smax) {
   constexpr bool KEEP = NB <= kDuoZeilDpp;
-  DuoZeilBest<D> best;
+  ZeilBest<D> best;
 #pragma unroll
   for (int k = 0; k < D; ++k) best.bd[k] = 0.0f;
   if constexpr (KEEP) {
@@ -489,10 +430,10 @@ __device__ __forceinline__ int duo_zeillinger(const float (&q)[CH * D], int h, f
     for (int a = 0; a < NB; ++a) {
 #pragma unroll
       for (int b = a + 1; b < NB; ++b)
-        duo_zeil_pair<D, true>(best, &q[a * D], &q[b * D], true, (128 * a + 2 * b) + 65 * h);
+        zeil_pair<D, true>(best, &q[a * D], &q[b * D], true, (128 * a + 2 * b) + 65 * h);
 #pragma unroll
       for (int b = a; b < NB; ++b)
-        duo_zeil_pair<D, true>(best, &q[a * D], &p[b * D], (b > a) | (h == 0), (128 * a + 2 * b + 1) + 63 * h);
+        zeil_pair<D, true>(best, &q[a * D], &p[b * D], (b > a) | (h == 0), (128 * a + 2 * b + 1) + 63 * h);
       if constexpr (NB > 3) __builtin_amdgcn_sched_barrier(0);
     }
   } else {
@@ -505,7 +446,7 @@ __device__ __forceinline__ int duo_zeillinger(const float (&q)[CH * D], int h, f
     const int n = 2 * smax;  // ranks in use (wave-uniform); holes are +inf
     // two pairs per pass with a best of their own each (two independent chains; the order of the merges does not
     // matter: the pair index is part of the key)
-    DuoZeilBest<D> second;
+    ZeilBest<D> second;
 #pragma nounroll
     for (int i = h; i + 1 < n; i += 2) {
       float pi[D];
@@ -520,21 +461,21 @@ __device__ __forceinline__ int duo_zeillinger(const float (&q)[CH * D], int h, f
           pj[k] = mine[j * D + k];
           pk[k] = mine[j2 * D + k];
         }
-        duo_zeil_pair<D, false>(best, pi, pj, true, 64 * i + j);
-        duo_zeil_pair<D, false>(second, pi, pk, j + 1 < n, 64 * i + j + 1);
+        zeil_pair<D, false>(best, pi, pj, true, 64 * i + j);
+        zeil_pair<D, false>(second, pi, pk, j + 1 < n, 64 * i + j + 1);
       }
     }
-    duo_zeil_merge<D, false>(best, second);
+    zeil_merge<D, false>(best, second);
   }
   {  // the partner's best
-    DuoZeilBest<D> o;
+    ZeilBest<D> o;
     o.hi = (uint32_t)duo_other_i((int)best.hi);
     o.lo = (uint32_t)duo_other_i((int)best.lo);
     if constexpr (KEEP) {
 #pragma unroll
       for (int k = 0; k < D; ++k) o.bd[k] = duo_other(best.bd[k]);
     }
-    duo_zeil_merge<D, KEEP>(best, o);
+    zeil_merge<D, KEEP>(best, o);
   }
   const bool have = best.hi != 0xFFFFFFFFu;
   if constexpr (!KEEP) {  // the chosen pair's difference from the parked rows
@@ -870,6 +811,7 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
         int axis;
         if constexpr (ZEIL) {
           // (a game with fewer than two rows has no pair: class 0 -- a wave of finished games skips the test)
+          static_assert(NB <= kDuoZeilDpp || 2 * NB <= M, "the rolled pair loop parks ranks 0 .. 2 NB - 1 in the game's M rows");
           const int zc = __any(active && np >= 2) ? duo_zeillinger<CH, D, NB>(q, h, mine, smax) : 0;
           uint32_t ra, rb;
           int cls;

@@ -538,4 +538,64 @@ __device__ __forceinline__ int c_zeillinger(const float (&q)[C * D], int nmax, b
   return encode_mask((1u << lo) | (1u << hi));
 }
 
+// ---- Zeillinger's pair test for the kernels that split a game over lanes (hk_duo_kernel.h, hk_quadroll_kernel.h) ------
+// The best pair so far as ONE comparable key: hi = the bits of L (a non-negative finite float: its bit pattern orders
+// like its value), lo = S << 16 | 64 i + j -- "smaller (L, S), then the earlier pair" is an unsigned compare of (hi, lo).
+template <int D>
+struct ZeilBest {
+  uint32_t hi = 0xFFFFFFFFu, lo = 0xFFFFFFFFu;  // (all ones: none yet)
+  float bd[D];                                  // the pair's difference (KEEP; else re-read from the parked rows)
+};
+
+// one pair (mine = the earlier row i, other = row j): its characteristic vector against the best so far.  ~25
+// instructions: max / min / median of three are single instructions, #max + #min = 2 + (median == max) + (median == min)
+// in dimension 3; every term is bitwise (with && / || the compiler made each one a branch on the exec mask: 14 per pair)
+template <int D, bool KEEP>
+__device__ __forceinline__ void zeil_pair(ZeilBest<D>& best, const float* mine, const float* other, bool ok, int idx) {
+  float v[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) v[k] = mine[k] - other[k];
+  float mx, mn;
+  uint32_t cnt;
+  if constexpr (D == 3) {
+    mx = __builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]);
+    mn = __builtin_fminf(__builtin_fminf(v[0], v[1]), v[2]);
+    const float md = __builtin_amdgcn_fmed3f(v[0], v[1], v[2]);
+    cnt = 2u + (uint32_t)(md == mx) + (uint32_t)(md == mn);
+  } else {
+    mx = v[0];
+    mn = v[0];
+#pragma unroll
+    for (int k = 1; k < D; ++k) {
+      mx = __builtin_fmaxf(mx, v[k]);
+      mn = __builtin_fminf(mn, v[k]);
+    }
+    cnt = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) cnt += (uint32_t)(v[k] == mx) + (uint32_t)(v[k] == mn);
+  }
+  const float L = mx - mn;
+  const bool close = fabsf(L) <= 1e-8f + 1e-5f * fabsf(mn);  // jnp.isclose(max, min)
+  const bool valid = ok & (mine[0] < INFINITY) & (other[0] < INFINITY) & !close;
+  const uint32_t khi = __float_as_uint(L), klo = (cnt << 16) | (uint32_t)idx;
+  const bool better = valid & ((khi < best.hi) | ((khi == best.hi) & (klo < best.lo)));
+  best.hi = better ? khi : best.hi;
+  best.lo = better ? klo : best.lo;
+  if constexpr (KEEP) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) best.bd[k] = better ? v[k] : best.bd[k];
+  }
+}
+
+template <int D, bool KEEP>
+__device__ __forceinline__ void zeil_merge(ZeilBest<D>& best, const ZeilBest<D>& o) {
+  const bool take = (o.hi < best.hi) | ((o.hi == best.hi) & (o.lo < best.lo));
+  best.hi = take ? o.hi : best.hi;
+  best.lo = take ? o.lo : best.lo;
+  if constexpr (KEEP) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) best.bd[k] = take ? o.bd[k] : best.bd[k];
+  }
+}
+
 }  // namespace hk

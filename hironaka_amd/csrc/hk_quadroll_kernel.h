@@ -239,13 +239,84 @@ __device__ __forceinline__ void qr_build_image(const float (&q)[R * D], const in
   wave_lds_fence();
 }
 
+// ZEIL: Zeillinger's host (jax/players.py:55-109) on four lanes per game -- the quad parks its rows by rank (4 s + j)
+// in the compact image (scratch between the stages), lane j takes the rows i = j, j + 4, ... against every later row as
+// a rolled loop, two pairs per pass (hk_fast_rows.h: zeil_pair, one packed key (L, S, pair index)); the four bests
+// merge through two DPP rotations; the chosen pair's difference is re-read from the parked rows.  hk_duo_kernel.h has
+// the two-lane twin.
+template <int M, int CW, int R, int D>
+__device__ __forceinline__ int qr_zeillinger(const float (&q)[R * D], float* cmine, int j, int smax) {
+  wave_lds_fence();
+  unrolled_while<0, R>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (s >= smax) return false;
+    if (kQuad * s + j < M) {  // (ranks past the game's M rows do not exist: the image holds M rows per game)
+      float* dst = cmine + (kQuad * s + j) * CW;
+      if constexpr (D == 4) {
+        *reinterpret_cast<vf4*>(dst) = vf4{q[s * D], q[s * D + 1], q[s * D + 2], q[s * D + 3]};
+      } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) dst[k] = q[s * D + k];
+      }
+    }
+    return true;
+  });
+  wave_lds_fence();
+  const int n = (kQuad * smax < M) ? kQuad * smax : M;  // ranks in use (wave-uniform); holes are +inf
+  ZeilBest<D> best, second;
+#pragma nounroll
+  for (int i = j; i + 1 < n; i += kQuad) {
+    float pi[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) pi[k] = cmine[i * CW + k];
+#pragma nounroll
+    for (int jj = i + 1; jj < n; jj += 2) {
+      float pj[D], pk[D];
+      const int j2 = (jj + 1 < n) ? jj + 1 : jj;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        pj[k] = cmine[jj * CW + k];
+        pk[k] = cmine[j2 * CW + k];
+      }
+      zeil_pair<D, false>(best, pi, pj, true, 64 * i + jj);
+      zeil_pair<D, false>(second, pi, pk, jj + 1 < n, 64 * i + jj + 1);
+    }
+  }
+  zeil_merge<D, false>(best, second);
+  {
+    ZeilBest<D> o;
+    o.hi = (uint32_t)qperm_i<kQuadUp1>((int)best.hi);
+    o.lo = (uint32_t)qperm_i<kQuadUp1>((int)best.lo);
+    zeil_merge<D, false>(best, o);
+    o.hi = (uint32_t)qperm_i<kQuadUp2>((int)best.hi);
+    o.lo = (uint32_t)qperm_i<kQuadUp2>((int)best.lo);
+    zeil_merge<D, false>(best, o);
+  }
+  const bool have = best.hi != 0xFFFFFFFFu;
+  const int bi = have ? (int)((best.lo & 0xFFFFu) >> 6) : 0, bj = have ? (int)(best.lo & 63u) : 0;
+  float bd[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) bd[k] = cmine[bi * CW + k] - cmine[bj * CW + k];
+  wave_lds_fence();  // (the stages park rows here again)
+  int lo = 0, hi = 0;
+  float vlo = bd[0], vhi = bd[0];
+#pragma unroll
+  for (int k = 1; k < D; ++k) {
+    if (bd[k] < vlo) { vlo = bd[k]; lo = k; }
+    if (bd[k] > vhi) { vhi = bd[k]; hi = k; }
+  }
+  if (!have || lo == hi) return 0;
+  return encode_mask((1u << lo) | (1u << hi));
+}
+
 // REC: the recording rollout -- per step the observation (the state before the step, rebuilt from the rows in
 // registers and stored as one slab) and / or the small records (host class, axis, done, reward) -- what the
 // simulate-shaped consumers read (hironaka/jax/simulation_fn.py:196-211).  Once every game of the wave is at its
 // fixed point only the stores go on (the same image, the policies' draws, done = 1, reward = 0).
-template <int M, int D, int HOT, int WPB, bool REC = false>
+template <int M, int D, int HOT, int WPB, bool REC = false, bool ZEIL = false>
 __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) void quadroll_kernel(
     const float* in0, int64_t in_stride0, int batch0, const Params prm) {
+  static_assert(!ZEIL || (!REC && HOT == kHotNone), "Zeillinger's host: plain rollouts, policies inside the loop");
   using G = QuadGeom<M, D>;
   using RG = QuadRollGeom<M, D>;
   constexpr int R = RG::R, CW = RG::CW;
@@ -280,7 +351,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   const uint64_t gg0 = prm.game_offset + (uint64_t)g0;
   uint32_t wb0 = step0 >> 2;  // first Philox block of the window (wave-uniform)
   const uint32_t wb_last = nsteps > 0 ? (step0 + (uint32_t)nsteps - 1u) >> 2 : wb0;
-  {
+  if constexpr (!ZEIL) {
     const uint32_t nb = wb_last - wb0 + 1u;
     qr_policy_fill<D>(act, gg0, wb0, (int)(nb < (uint32_t)kQrBlocks ? nb : (uint32_t)kQrBlocks), seed, host_policy,
                       agent_policy, lane);
@@ -360,7 +431,8 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
           wave_lds_fence();
         }
       }
-      fast_policy<D>(seed, host_policy, agent_policy, gg, step0 + (uint32_t)t, pcache, cls, axis, mask, 0);
+      const int zc = (host_policy == HK_HOST_ZEILLINGER && leader) ? zeillinger_game<float>(mine, prm.m, prm.d) : 0;
+      fast_policy<D>(seed, host_policy, agent_policy, gg, step0 + (uint32_t)t, pcache, cls, axis, mask, zc);
       const bool prev_done = np < 2;
       if (leader) {
         for (int k = 0; k < prm.d; ++k) cs[k] = (float)((mask >> k) & 1u);
@@ -493,8 +565,9 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   };
   int t = 0;
   bool stop = false;
+  PolicyCache zcache;  // (ZEIL: the lane's own Philox block, one per four steps)
   while (t < nsteps && !stop) {  // one pass per window of actions (episodes of up to 24 steps: one pass)
-    if ((uint32_t)((step0 + (uint32_t)t) >> 2) - wb0 >= (uint32_t)kQrBlocks) {
+    if (!ZEIL && (uint32_t)((step0 + (uint32_t)t) >> 2) - wb0 >= (uint32_t)kQrBlocks) {
       if constexpr (REC) flush_records(t, length);
       wave_lds_fence();
       wb0 = (step0 + (uint32_t)t) >> 2;
@@ -505,16 +578,27 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
     }
     const uint32_t wstep0 = wb0 << 2;                       // first step of the window
     const uint32_t wleft = wstep0 + (uint32_t)kQrSteps - step0;  // steps (from 0) the window reaches
-    const int tw = (wleft < (uint32_t)nsteps) ? (int)wleft : nsteps;
+    const int tw = (!ZEIL && wleft < (uint32_t)nsteps) ? (int)wleft : nsteps;
     const uint8_t* arow = act + gi;
     QuadLevels<M, D, R>::run([&](auto nbc, auto loc) {
       constexpr int NB = decltype(nbc)::value, LO = decltype(loc)::value;
       // (no s_setprio by bucket here: with three or four waves per SIMD it starves the others -- measured 24.4 -> 26.5 us
       // at (20,3) x 65 536, 192 -> 202 us at (50,4) x 262 144; hk_duo_kernel.h, two waves per SIMD, gains 3 % from it)
       while (t < tw && (smax > LO || LO == 0) && !stop) {  // (a wave of empty games has smax 1: the last loop's)
-        const uint32_t a = arow[(int)(step0 + (uint32_t)t - wstep0) * kQuadGames];
-        const uint32_t cmask = a & 31u;
-        const int axis = (int)(a >> 5);
+        uint32_t cmask;
+        int axis;
+        if constexpr (ZEIL) {
+          // (a game with fewer than two rows has no pair: class 0 -- a wave of finished games skips the test)
+          const int zc = __any(active && np >= 2) ? qr_zeillinger<M, CW, R, D>(q, cmine, j, smax) : 0;
+          uint32_t ra, rb;
+          int cls;
+          policy_words(gg0 + (uint64_t)gi, step0 + (uint32_t)t, seed, zcache, D, ra, rb);
+          policy_from_words<D>(ra, rb, host_policy, agent_policy, cls, axis, cmask, zc);
+        } else {
+          const uint32_t a = arow[(int)(step0 + (uint32_t)t - wstep0) * kQuadGames];
+          cmask = a & 31u;
+          axis = (int)(a >> 5);
+        }
         if constexpr (REC) {
           if (want_obs) {  // the state before the step
             qr_build_image<M, D, R>(q, orig, region, mine, smax, pad, lane);
@@ -591,7 +675,10 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
 inline bool quadroll_request_ok(const Params& prm) {
   if (prm.mode != kModeRollout || prm.m > 255) return false;
   if (prm.game_ids) return false;  // (re-ordered batches: two-lane / one-lane / generic kernels)
-  if (prm.host_policy == HK_HOST_ZEILLINGER) return false;
+  // Zeillinger's host: plain rollouts (quadroll_kernel<..., ZEIL>)
+  if (prm.host_policy == HK_HOST_ZEILLINGER &&
+      (prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out))
+    return false;
   if ((prm.stages & HK_STAGE_NEWTON) &&
       ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)))
     return false;
@@ -620,7 +707,10 @@ int launch_quadroll_t(Params prm, hipStream_t stream) {
                          (const float*)prm.in, prm.in_stride, prm.batch, prm);
     return launch_status();
   }
-  if (hot == kHotJax)
+  if (prm.host_policy == HK_HOST_ZEILLINGER)
+    hipLaunchKernelGGL((quadroll_kernel<M, D, kHotNone, WPB, false, true>), dim3(grid), dim3(kWave * WPB), 0, stream,
+                       (const float*)prm.in, prm.in_stride, prm.batch, prm);
+  else if (hot == kHotJax)
     hipLaunchKernelGGL((quadroll_kernel<M, D, kHotJax, WPB>), dim3(grid), dim3(kWave * WPB), 0, stream,
                        (const float*)prm.in, prm.in_stride, prm.batch, prm);
   else if (hot == kHotTorch)
@@ -649,6 +739,9 @@ inline bool quadroll_supported(const Params& prm, int dtype) {
 // against 114 / 279 us at 262 144).
 inline bool quadroll_default(const Params& prm, int simds, bool small_records_elsewhere = false) {
   if (prm.m > 32) return true;
+  // Zeillinger's host: the two-lane kernel is ahead at every size it serves (scripts/probe_zeillinger.py, (20,3):
+  // 40.9 against 44.3 us at 32 768 games, 37.4 against 38.5 at 8 192, 44.2 against 57.0 at 65 536)
+  if (prm.host_policy == HK_HOST_ZEILLINGER) return false;
   if (prm.obs_out) return true;
   if ((prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out) && !small_records_elsewhere) return true;
   const int64_t waves = ((int64_t)prm.batch + kQuadGames - 1) / kQuadGames;

@@ -7,12 +7,13 @@ from hironaka_amd import ops, _abi as A
 from probe_records import timed
 
 if __name__ == "__main__":
-    for b, m, d in ((65536, 20, 3), (8192, 20, 3), (262144, 50, 4)):
+    for b, m, d in ((65536, 20, 3), (32768, 20, 3), (8192, 20, 3), (262144, 50, 4)):
         P = ops.generate_points(b, m, d, 20, seed=42)
         Q = torch.empty_like(P)
         ws = ops.rollout_workspace(b, 20, (m, d))
         out = []
-        for name, fl in (("default", 0), ("one", A.HK_FLAG_FORCE_ONE_LANE), ("team", A.HK_FLAG_FORCE_TEAM)):
+        for name, fl in (("default", 0), ("four", A.HK_FLAG_FORCE_FOUR_LANES), ("two", A.HK_FLAG_FORCE_TWO_LANES),
+                         ("one", A.HK_FLAG_FORCE_ONE_LANE), ("team", A.HK_FLAG_FORCE_TEAM)):
             def ep():
                 for _ in range(3):
                     ops.rollout(Q, 20, 1, initial=P, defer_counts=True, workspace=ws, flags=fl,

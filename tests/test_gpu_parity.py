@@ -456,11 +456,11 @@ def test_small_records_without_observations_match_oracle(spec):
             assert np.array_equal(host(got[k]), want[k]), k
 
 
-@pytest.mark.parametrize("spec", [(20, 3), (10, 3), (4, 3), (5, 3), (16, 3), (8, 4), (20, 4)])
+@pytest.mark.parametrize("spec", [(20, 3), (10, 3), (4, 3), (5, 3), (16, 3), (8, 4), (20, 4), (50, 4)])
 def test_zeillinger_host_plain_rollouts_match_oracle(spec):
     """Plain rollouts against Zeillinger's host (jax/players.py:55-109) on the two-lane kernel (`duo_kernel<..., ZEIL>`:
-    the pair test split over the two lanes of a game, ties by the explicit pair index) and on the one-lane kernel,
-    against the oracle: wide states (every bucket of the staircase), states of small integers (many equal
+    the pair test split over the two lanes of a game, ties by the explicit pair index), the four-lane kernel
+    (`quadroll_kernel<..., ZEIL>`: the default at (50,4) and for small batches) and the one-lane kernel, against the oracle: wide states (every bucket of the staircase), states of small integers (many equal
     characteristic vectors: the first pair in row-major order must win), ragged waves, a step offset inside a Philox
     block, one game off the exact path."""
     m, d = spec
@@ -474,7 +474,9 @@ def test_zeillinger_host_plain_rollouts_match_oracle(spec):
             for T, so in ((20, 0), (11, 6)):
                 want_p, want = CO.rollout(p0, T, 13, game_offset=9, step_offset=so, host_policy=A.HK_HOST_ZEILLINGER,
                                           agent_policy=ap, record=False)
-                for fl in (0, A.HK_FLAG_FORCE_TWO_LANES, A.HK_FLAG_FORCE_ONE_LANE):
+                for fl in (0, A.HK_FLAG_FORCE_TWO_LANES, A.HK_FLAG_FORCE_FOUR_LANES, A.HK_FLAG_FORCE_ONE_LANE):
+                    if m > 32 and fl in (A.HK_FLAG_FORCE_TWO_LANES, A.HK_FLAG_FORCE_ONE_LANE):
+                        continue
                     P = dev(p0.copy())
                     got = ops.rollout(P, T, 13, game_offset=9, step_offset=so, host_policy=A.HK_HOST_ZEILLINGER,
                                       agent_policy=ap, flags=fl, record=("game_length",))
