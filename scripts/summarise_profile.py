@@ -23,10 +23,12 @@ dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 # the launches bench.py's headline numbers come from (kernel name pattern, grid size in threads)
-ROLLOUT = (re.compile(r"duo_kernel<20, 3, 1, 1(, false)?>"), "131072")   # fused rollout, 65 536 games, two lanes per game
-STEP = (re.compile(r"quad_kernel<20, 3, 1, \d, 1(, false)?>"), "262144")  # hk_step (JAX-trainer configuration, f32 mask + i32 axis)
-STEP3 = (re.compile(r"quad_kernel<50, 4, 1, \d, 1(, false)?>"), "1048576")  # hk_step at (50,4) x 262 144
-ROLL3 = (re.compile(r"quadroll_kernel<50, 4, 1, 1(, false)?>"), "1048576")  # fused rollout at (50,4) x 262 144
+ROLLOUT = (re.compile(r"duo_kernel<20, 3, 1, 1(, false)*>"), "131072")   # fused rollout, 65 536 games, two lanes per game
+STEP = (re.compile(r"quad_kernel<20, 3, 1, \d, 1(, false)*>"), "262144")  # hk_step (JAX-trainer configuration, f32 mask + i32 axis)
+STEP3 = (re.compile(r"quad_kernel<50, 4, 1, \d, 1(, false)*>"), "1048576")  # hk_step at (50,4) x 262 144
+ROLL3 = (re.compile(r"quadroll_kernel<50, 4, 1, 1(, false)*>"), "1048576")  # fused rollout at (50,4) x 262 144
+# one in-kernel-policy step of 65 536 games (rollouts of <= 6 steps run on the four-lane kernel since round 3)
+SINGLE = (re.compile(r"quadroll_kernel<20, 3, 1, 4(, false)*>"), "262144")
 
 
 def short(name):
@@ -68,7 +70,7 @@ if trace:
     lines.append("kernel,grid_threads,calls,mean_us,p50_us,p95_us")
     for (k, grid), v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
         v = np.array(v)
-        is_rollout = re.search(r"(fast|duo)_kernel<\d+, \d+, 1, \d(, false)?>", k) is not None
+        is_rollout = re.search(r"(fast|duo)_kernel<\d+, \d+, 1, \d(, false)*>", k) is not None
         parts = (("T=20 episodes", None), ("T=1 steps", None)) if is_rollout else (("", None),)
         if is_rollout:
             big, small = split_rollout(v)
@@ -148,7 +150,7 @@ out = {"source": f"rocprofv3 --pmc passes (separate runs), profiles/{tag}_pmc_su
        "batch": 65536, "max_points": 20, "dim": 3,
        "rollout_T20_bytes_per_launch": traffic(ROLLOUT, "[T=20]"),
        "rollout_T20_valu_insts_per_launch": find(ROLLOUT, "[T=20]", "SQ_INSTS_VALU"),
-       "single_step_bytes_per_launch": traffic(ROLLOUT, "[T=1]"),
+       "single_step_bytes_per_launch": traffic(ROLLOUT, "[T=1]") or traffic(SINGLE),
        "boundary_step_bytes_per_launch": traffic(STEP),
        "boundary_step_valu_insts_per_launch": find(STEP, "", "SQ_INSTS_VALU"),
        "boundary_step_wait_any_frac": (find(STEP, "", "SQ_WAIT_ANY") or 0) / (find(STEP, "", "SQ_WAVE_CYCLES") or 1),
