@@ -123,11 +123,11 @@ __device__ __forceinline__ int qr_stages(float (&q)[R * D], uint32_t cmask, int 
 // the decoded actions of blocks [wb0, wb0 + nb) of the wave's 16 games: lane l serves game l & 15, blocks (l >> 4) + 4 i.
 // One byte per game and step: subset mask | axis << 5.
 template <int D>
-__device__ __forceinline__ void qr_policy_fill(uint8_t* act, uint64_t gg0, uint32_t wb0, int nb, uint64_t seed,
+__device__ __forceinline__ void qr_policy_fill(uint8_t* act, uint64_t gg, uint32_t wb0, int nb, uint64_t seed,
                                                int host_policy, int agent_policy, int lane) {
+  // gg: the policy stream's index of game (lane & 15) of the wave -- the lane's FILL game, not the game it plays
   static_assert(D <= kPolicyShortDim, "four steps per Philox block (hk_common.h policy_words)");
   const int game = lane & (kQuadGames - 1), sub = lane >> 4;
-  const uint64_t gg = gg0 + (uint64_t)game;
 #pragma nounroll
   for (int i = 0; i < kQrBlocks; i += 4) {
     if (i >= nb) break;  // wave-uniform
@@ -337,7 +337,16 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   const bool active = gi < ngames;
   const bool leader = active && j == 0;
   const int64_t g = g0 + gi;
+  // hk_rollout_desc.game_ids (a re-ordered batch keeps every game's policy stream): the id of the lane's FILL game
+  // (lane & 15: the game whose action bytes it computes), requested before the slab and not touched until the slab's
+  // requests are out (hk_duo_kernel.h); the id of the game the lane plays comes from that lane when it is needed
+  const bool has_ids = prm.game_ids != nullptr;
+  const int fill_game = lane & (kQuadGames - 1);
+  uint32_t raw_id = 0;
+  if (has_ids && fill_game < ngames) raw_id = (uint32_t)prm.game_ids[g0 + fill_game];
+  __builtin_amdgcn_sched_barrier(0);
   quad_slab_load<M, D>(in0 + g0 * G::N, region, ngames, lane);
+  __builtin_amdgcn_sched_barrier(0);
   const float pad = prm.pad_f32;
   const unsigned flags = (HOT == kHotJax) ? (unsigned)HK_SEM_JAX : (HOT == kHotTorch) ? kHotTorchFlags : prm.flags;
   const unsigned stages = HOT ? (unsigned)(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON) : prm.stages;
@@ -348,12 +357,12 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   int host_policy = prm.host_policy, agent_policy = prm.agent_policy;
   asm volatile("" : "+s"(step0), "+s"(seed), "+s"(host_policy), "+s"(agent_policy));
   // the first window of decoded actions, computed while the slab is in flight
-  const uint64_t gg0 = prm.game_offset + (uint64_t)g0;
+  const uint64_t gg_fill = prm.game_offset + (has_ids ? (uint64_t)raw_id : (uint64_t)(g0 + fill_game));
   uint32_t wb0 = step0 >> 2;  // first Philox block of the window (wave-uniform)
   const uint32_t wb_last = nsteps > 0 ? (step0 + (uint32_t)nsteps - 1u) >> 2 : wb0;
   if constexpr (!ZEIL) {
     const uint32_t nb = wb_last - wb0 + 1u;
-    qr_policy_fill<D>(act, gg0, wb0, (int)(nb < (uint32_t)kQrBlocks ? nb : (uint32_t)kQrBlocks), seed, host_policy,
+    qr_policy_fill<D>(act, gg_fill, wb0, (int)(nb < (uint32_t)kQrBlocks ? nb : (uint32_t)kQrBlocks), seed, host_policy,
                       agent_policy, lane);
   }
   float* mine = region + gi * G::N;
@@ -413,7 +422,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
     // ---- slow path (whole wave): the quad's first lane runs the exact generic routines on the image -----------------
     wave_lds_fence();
     float* cs = reinterpret_cast<float*>(act) + gi * D;
-    const uint64_t gg = prm.game_offset + (uint64_t)g;
+    const uint64_t gg = prm.game_offset + (has_ids ? (uint64_t)(uint32_t)__shfl((int)raw_id, gi) : (uint64_t)g);
     PolicyCache pcache;
     np = leader ? num_points<float>(mine, M, D) : 2;
     int length = (np < 2) ? 0 : -1;
@@ -566,13 +575,15 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   int t = 0;
   bool stop = false;
   PolicyCache zcache;  // (ZEIL: the lane's own Philox block, one per four steps)
+  const uint64_t gg_game =  // (ZEIL) the policy stream's index of the game this lane plays
+      ZEIL ? prm.game_offset + (has_ids ? (uint64_t)(uint32_t)__shfl((int)raw_id, gi) : (uint64_t)g) : 0;
   while (t < nsteps && !stop) {  // one pass per window of actions (episodes of up to 24 steps: one pass)
     if (!ZEIL && (uint32_t)((step0 + (uint32_t)t) >> 2) - wb0 >= (uint32_t)kQrBlocks) {
       if constexpr (REC) flush_records(t, length);
       wave_lds_fence();
       wb0 = (step0 + (uint32_t)t) >> 2;
       const uint32_t nb = wb_last - wb0 + 1u;
-      qr_policy_fill<D>(act, gg0, wb0, (int)(nb < (uint32_t)kQrBlocks ? nb : (uint32_t)kQrBlocks), seed, host_policy,
+      qr_policy_fill<D>(act, gg_fill, wb0, (int)(nb < (uint32_t)kQrBlocks ? nb : (uint32_t)kQrBlocks), seed, host_policy,
                         agent_policy, lane);
       wave_lds_fence();
     }
@@ -592,7 +603,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
           const int zc = __any(active && np >= 2) ? qr_zeillinger<M, CW, R, D>(q, cmine, j, smax) : 0;
           uint32_t ra, rb;
           int cls;
-          policy_words(gg0 + (uint64_t)gi, step0 + (uint32_t)t, seed, zcache, D, ra, rb);
+          policy_words(gg_game, step0 + (uint32_t)t, seed, zcache, D, ra, rb);
           policy_from_words<D>(ra, rb, host_policy, agent_policy, cls, axis, cmask, zc);
         } else {
           const uint32_t a = arow[(int)(step0 + (uint32_t)t - wstep0) * kQuadGames];
@@ -654,7 +665,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
         wave_lds_fence();
         wb0 = (step0 + (uint32_t)t) >> 2;
         const uint32_t nb = wb_last - wb0 + 1u;
-        qr_policy_fill<D>(act, gg0, wb0, (int)(nb < (uint32_t)kQrBlocks ? nb : (uint32_t)kQrBlocks), seed, host_policy,
+        qr_policy_fill<D>(act, gg_fill, wb0, (int)(nb < (uint32_t)kQrBlocks ? nb : (uint32_t)kQrBlocks), seed, host_policy,
                           agent_policy, lane);
         wave_lds_fence();
       }
@@ -674,7 +685,6 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
 // rollouts (no Zeillinger host, no sorted output) of float32, contiguous, W-aligned records
 inline bool quadroll_request_ok(const Params& prm) {
   if (prm.mode != kModeRollout || prm.m > 255) return false;
-  if (prm.game_ids) return false;  // (re-ordered batches: two-lane / one-lane / generic kernels)
   // Zeillinger's host: plain rollouts (quadroll_kernel<..., ZEIL>)
   if (prm.host_policy == HK_HOST_ZEILLINGER &&
       (prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out))

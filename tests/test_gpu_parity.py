@@ -489,8 +489,8 @@ def test_zeillinger_host_plain_rollouts_match_oracle(spec):
 def test_reordered_batch_with_game_ids_rolls_out_like_the_original(spec):
     """`hk_rollout_desc.game_ids` (round 3): a batch binned by live rows (`ops.bin_by_live_rows`) with the permutation as
     game ids gives, game by game, what the original order gives -- against the oracle with the same ids, and as the
-    permutation of the plain run; every family that serves re-ordered batches (two lanes, one lane, team, generic; the
-    four-lane and pool kernels step aside), records included."""
+    permutation of the plain run; every family (four lanes, two lanes, one lane, team, generic; the pool kernel steps
+    aside), records included."""
     m, d = spec
     p0 = CO.generate_points(32 * 9 + 5, m, d, 20, 21)
     P0 = dev(p0.copy())
@@ -509,8 +509,9 @@ def test_reordered_batch_with_game_ids_rolls_out_like_the_original(spec):
             # the oracle itself: the re-ordered run is the permutation of the plain one
             assert np.array_equal(want_p, plain_p[idn]) and np.array_equal(want["game_length"], plain["game_length"][idn])
             assert np.array_equal(want["done_count"], plain["done_count"])
-            for fl in (0, A.HK_FLAG_FORCE_TWO_LANES, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC):
-                if fl == A.HK_FLAG_FORCE_TWO_LANES and (m > 32 or hp == A.HK_HOST_ZEILLINGER):
+            for fl in (0, A.HK_FLAG_FORCE_FOUR_LANES, A.HK_FLAG_FORCE_TWO_LANES, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_TEAM,
+                       A.HK_FLAG_FORCE_GENERIC):
+                if fl == A.HK_FLAG_FORCE_TWO_LANES and m > 32:
                     continue
                 for rec in (fields, ("obs",) + fields, ("game_length",)):
                     Q = binned.clone()
