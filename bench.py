@@ -572,6 +572,16 @@ def main():
                                   MIN_SECTION_S)
         r3, _, _ = timed_replays(capture(roll3).replay, MIN_SECTION_S)
         c3, _, _ = timed_replays(capture(lambda: out3.copy_(fresh3)).replay, MIN_SECTION_S)
+        binned3 = None
+        if not args.no_binned:  # the same episode on the batch binned by live rows, game ids keep the streams
+            b3_pts, b3_ids = ops.bin_by_live_rows(fresh3)
+
+            def roll3_binned():
+                ops.rollout(state3, EPISODE, SEED, done_count=dc3, initial=b3_pts, game_ids=b3_ids, stages=stages,
+                            host_policy=A.HK_HOST_RANDOM, agent_policy=A.HK_AGENT_RANDOM)
+            rb3, _, _ = timed_replays(capture(roll3_binned).replay, MIN_SECTION_S)
+            binned3 = rb3 * 1e6
+            del b3_pts, b3_ids
         config3 = {"workload": f"dim={d3}, max_points={m3}, batch={b3} (BASELINE configs[2])",
                    "hk_step_us": s3 / 5 * 1e6, "hk_step_env_steps_per_s": b3 * 5 / s3,
                    "roofline": hbm_roofline(s3 / 5, b3 * bs3, kernel="hk_step at (50,4) x 262144 from generate_pts states"),
@@ -579,6 +589,7 @@ def main():
                    "hk_step_dense_note": "50 live rows per game: 1225 pair tests per game, VALU-bound",
                    "state_copy_us": c3 * 1e6,
                    "fused_rollout_us_per_episode": r3 * 1e6, "fused_env_steps_per_s": b3 * EPISODE / r3,
+                   "fused_rollout_binned_by_live_rows_us_per_episode": binned3,
                    "algorithmic_bytes_per_env_step": bs3}
         del fresh3, out3, state3, dense3
 
