@@ -485,6 +485,29 @@ def test_zeillinger_host_plain_rollouts_match_oracle(spec):
                     assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"])
 
 
+@pytest.mark.parametrize("spec", [(20, 3), (50, 4), (8, 4)])
+def test_long_episodes_match_oracle(spec):
+    """Episodes of more than 64 steps (the finished-game counts go out 64 steps per atomic instruction, the action windows
+    and the small records window by window): every family, plain and with the small records, random and Zeillinger's host."""
+    m, d = spec
+    p0 = CO.generate_points(32 * 3 + 5, m, d, 20, 3)
+    small = ("host_class", "axis", "done", "reward", "game_length")
+    for T, so in ((130, 0), (67, 3)):
+        for hp in (A.HK_HOST_RANDOM, A.HK_HOST_ZEILLINGER):
+            want_p, want = CO.rollout(p0, T, 5, step_offset=so, host_policy=hp, agent_policy=A.HK_AGENT_RANDOM_LEGAL)
+            for fl in (0, A.HK_FLAG_FORCE_TWO_LANES, A.HK_FLAG_FORCE_FOUR_LANES, A.HK_FLAG_FORCE_ONE_LANE):
+                if m > 32 and fl in (A.HK_FLAG_FORCE_TWO_LANES, A.HK_FLAG_FORCE_ONE_LANE):
+                    continue
+                for rec in (("game_length",), small):
+                    P = dev(p0.copy())
+                    got = ops.rollout(P, T, 5, step_offset=so, host_policy=hp, agent_policy=A.HK_AGENT_RANDOM_LEGAL,
+                                      flags=fl, record=rec)
+                    assert np.array_equal(host(P), want_p), (T, hp, fl, rec)
+                    for k in rec:
+                        assert np.array_equal(host(got[k]), want[k]), (k, T, hp, fl)
+                    assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"]), (T, hp, fl)
+
+
 @pytest.mark.parametrize("spec", [(20, 3), (8, 4), (50, 4), (7, 3)])
 def test_reordered_batch_with_game_ids_rolls_out_like_the_original(spec):
     """`hk_rollout_desc.game_ids` (round 3): a batch binned by live rows (`ops.bin_by_live_rows`) with the permutation as
