@@ -485,6 +485,32 @@ def test_zeillinger_host_plain_rollouts_match_oracle(spec):
                     assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"])
 
 
+@pytest.mark.parametrize("spec", [(20, 3), (50, 4), (5, 3)])
+def test_tiny_batches_and_degenerate_episodes(spec):
+    """One game, a wave plus one game, no steps at all, one step, one step past an action window -- with game ids, every
+    family, plain / small records / everything recorded."""
+    m, d = spec
+    small = ("host_class", "axis", "done", "reward", "game_length")
+    for b in (1, 17, 65):
+        p0 = CO.generate_points(b, m, d, 20, 8)
+        ids = np.random.default_rng(b).permutation(b).astype(np.int32)
+        for T in (0, 1, 25):
+            for hp in (A.HK_HOST_RANDOM, A.HK_HOST_ZEILLINGER):
+                want_p, want = CO.rollout(p0, T, 5, step_offset=2, host_policy=hp, agent_policy=A.HK_AGENT_RANDOM, game_ids=ids)
+                for fl in (0, A.HK_FLAG_FORCE_TWO_LANES, A.HK_FLAG_FORCE_FOUR_LANES, A.HK_FLAG_FORCE_ONE_LANE,
+                           A.HK_FLAG_FORCE_POOL):
+                    if m > 32 and fl not in (0, A.HK_FLAG_FORCE_FOUR_LANES):
+                        continue
+                    for rec in (("game_length",), small, ("obs",) + small):
+                        P = dev(p0.copy())
+                        got = ops.rollout(P, T, 5, step_offset=2, host_policy=hp, agent_policy=A.HK_AGENT_RANDOM, flags=fl,
+                                          record=rec, game_ids=dev(ids))
+                        assert np.array_equal(host(P), want_p), (b, T, hp, fl, rec)
+                        for k in rec:
+                            assert np.array_equal(host(got[k]), want[k].reshape(got[k].shape)), (k, b, T, hp, fl)
+                        assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"])
+
+
 @pytest.mark.parametrize("spec", [(20, 3), (50, 4), (8, 4)])
 def test_long_episodes_match_oracle(spec):
     """Episodes of more than 64 steps (the finished-game counts go out 64 steps per atomic instruction, the action windows
