@@ -5,7 +5,7 @@ descriptors with host pointers) can import it without a GPU.
 """
 import ctypes as C
 
-HK_ABI_VERSION = 3
+HK_ABI_VERSION = 4
 
 # status codes
 HK_OK = 0
@@ -43,7 +43,6 @@ HK_FLAG_DEFER_COUNTS = 128
 HK_FLAG_FORCE_ONE_LANE = 256
 HK_FLAG_FORCE_TWO_LANES = 512
 HK_FLAG_FORCE_FOUR_LANES = 1024
-HK_FLAG_FORCE_POOL = 2048
 
 # fused policies
 HK_HOST_RANDOM, HK_HOST_ALL_COORD, HK_HOST_ZEILLINGER = 0, 1, 2
@@ -106,6 +105,11 @@ class hk_rollout_desc(C.Structure):
         ("stages", C.c_uint32),
         ("flags", C.c_uint32),
         ("game_ids", C.c_void_p),
+        ("gen_max_value", C.c_int32),
+        ("gen_stages", C.c_uint32),
+        ("gen_seed", C.c_uint64),
+        ("episodes", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
 

@@ -3,9 +3,9 @@
 // status code.  gfx950 only.
 #include "hk_fast_kernel.h"
 #include "hk_duo_kernel.h"
-#include "hk_pool_kernel.h"
 #include "hk_quad_kernel.h"
 #include "hk_quadroll_kernel.h"
+#include "hk_quadgen_kernel.h"
 #include "hk_team_kernel.h"
 #include "hk_search.h"
 #include "hk_generic_kernel.h"
@@ -66,7 +66,7 @@ int launch_generic(Params& prm, int dtype, hipStream_t stream) {
 // specialised shapes on HK_FLAG_FORCE_TEAM) -> generic kernel (anything else: f64, dim > 6, > 64 rows,
 // HK_FLAG_FORCE_GENERIC, and the few mode / semantics combinations fast_supported / team_supported decline)
 constexpr unsigned kHostSideFlags =
-    HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES | HK_FLAG_FORCE_FOUR_LANES | HK_FLAG_FORCE_POOL;  // kernel selection only
+    HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES | HK_FLAG_FORCE_FOUR_LANES;  // kernel selection only
 
 // hk_step on four lanes per game (hk_quad_kernel.h): where it is ahead of the two-lane kernel
 static bool use_quad(const Params& prm, int dtype) {
@@ -77,6 +77,12 @@ static bool use_quad(const Params& prm, int dtype) {
   }
   if (!quad_supported(prm, dtype)) return false;
   return quad_default(prm, device_simds());
+}
+// hk_generate_points on four lanes per game (hk_quadgen_kernel.h): everywhere it applies
+static bool use_quadgen(const Params& prm, int dtype) {
+  Params probe = prm;
+  probe.flags &= ~(unsigned)HK_FLAG_FORCE_FOUR_LANES;
+  return quadgen_supported(probe, dtype);
 }
 // plain rollouts on four lanes per game (hk_quadroll_kernel.h): forced, or where it is the default
 static bool use_duo(const Params& prm) { return !(prm.flags & HK_FLAG_FORCE_ONE_LANE) && duo_wanted(prm); }
@@ -91,14 +97,6 @@ static bool use_quadroll(const Params& prm, int dtype) {
   const bool duo_takes = small_only && fast_supported(prm, dtype) && use_duo(prm);
   return quadroll_default(prm, device_simds(), duo_takes);
 }
-// plain rollouts on the pool kernel (hk_pool_kernel.h): forced, or where it is ahead of the fixed deals
-static bool use_pool(const Params& prm) {
-  if (!pool_supported(prm)) return false;
-  if (prm.flags & HK_FLAG_FORCE_POOL) return true;
-  if (prm.flags & (HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES)) return false;
-  return pool_default(prm, device_simds());
-}
-
 int launch(Params& prm, int dtype, hipStream_t stream) {
   if (prm.batch == 0) return HK_OK;
   if (use_quad(prm, dtype)) {
@@ -109,13 +107,16 @@ int launch(Params& prm, int dtype, hipStream_t stream) {
     prm.flags &= ~kHostSideFlags;  // (the compiled rollout configurations compare flags)
     return launch_quadroll(prm, stream);
   }
+  if (use_quadgen(prm, dtype)) {
+    prm.flags &= ~kHostSideFlags;
+    return launch_quadgen(prm, stream);
+  }
   // (the agent's move as an argmax of its logits is decoded by the four-lane kernel only)
   if ((prm.stages & HK_STAGE_SHIFT) && prm.axis_dtype == HK_AXIS_MASKED_LOGITS) return HK_ERR_UNSUPPORTED;
   if (fast_supported(prm, dtype)) {
-    const bool pool = use_pool(prm);
     const bool duo = use_duo(prm);
     prm.flags &= ~kHostSideFlags;  // (the compiled rollout configurations compare flags)
-    return pool ? launch_pool(prm, stream) : duo ? launch_duo(prm, stream) : launch_fast(prm, stream);
+    return duo ? launch_duo(prm, stream) : launch_fast(prm, stream);
   }
   prm.flags &= ~kHostSideFlags;
   if (team_supported(prm, dtype)) {
@@ -130,7 +131,7 @@ int64_t planned_grid(Params prm, int dtype) {
   if (prm.batch == 0) return 0;
   if (use_quadroll(prm, dtype)) return quadroll_grid(prm);
   if (fast_supported(prm, dtype)) {
-    const int gpb = use_pool(prm) ? kPoolGames : use_duo(prm) ? kDuoGames : fast_games_per_block(prm);
+    const int gpb = use_duo(prm) ? kDuoGames : fast_games_per_block(prm);
     return ((int64_t)prm.batch + gpb - 1) / gpb;
   }
   if (team_supported(prm, dtype) && plan_team(prm) == HK_OK)
@@ -403,6 +404,7 @@ static int params_from_rollout(const hk_rollout_desc* r, Params& prm) {
   prm.game_length_out = r->game_length_out;
   prm.seed = r->seed;
   prm.game_offset = r->game_offset;
+  if (r->game_ids && !aligned(r->game_ids, 4)) return HK_ERR_ALIGN;
   prm.game_ids = r->game_ids;
   prm.step_offset = r->step_offset;
   prm.steps = r->steps;

@@ -162,6 +162,32 @@ __host__ __device__ inline uint32_t mulhi32(uint32_t r, uint32_t n) {
   return (uint32_t)(((uint64_t)r * n) >> 32);
 }
 
+// ---- the generator stream (DESIGN.md "Randomness"): element e = row * dim + coordinate of game gg ----------------------
+//   max_value <= kGenShortMax (round 4, ABI 4): Philox block (gg_lo, gg_hi, e >> 3, kStreamGenerate), word (e >> 1) & 3,
+//     its LOW half for even e, its HIGH half for odd e, value = (half * max_value) >> 16 -- eight elements per block: the
+//     draws of a fresh game are half of what generating it costs (a block is ~70 instructions, 20 of them slow 32 x 32 ->
+//     64 multiplies).  A 16-bit draw's bias is max_value / 2^16 < 0.1 % at the cap (0.03 % at the trainers' max_value 20);
+//   beyond: block e >> 2, word e & 3, value = mulhi32(word, max_value) -- four elements per block, as in ABI <= 3.
+constexpr int kGenShortMax = 64;
+__host__ __device__ inline bool gen_short(uint32_t max_value) { return max_value <= (uint32_t)kGenShortMax; }
+// the values of the elements a block serves, in element order: v[0..8) short, v[0..4) otherwise
+__host__ __device__ inline void gen_block_values(const U4& r, uint32_t max_value, bool short_form, uint32_t (&v)[8]) {
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+  if (short_form) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[2 * k] = ((w[k] & 0xFFFFu) * max_value) >> 16;
+      v[2 * k + 1] = ((w[k] >> 16) * max_value) >> 16;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = mulhi32(w[k], max_value);
+      v[4 + k] = 0u;
+    }
+  }
+}
+
 // ---- host action codec (jax/host_action_preprocess.py:8-24,78-87) -------------------------
 // class id -> bitmask (bit j <-> coordinate j): the cls-th integer >= 3 that is not a power of
 // two.  Integers with top bit L hold classes [2^L - L - 1, 2^(L+1) - L - 3].

@@ -437,14 +437,27 @@ __global__ __launch_bounds__(kWave, ((MODE == kModeRolloutRec || M * D > 64) ? 1
 
   // ---- 1. the image --------------------------------------------------------------------------------
   if (MODE == kModeGenerate) {
+    // (hk_common.h: eight elements per Philox block for small max_value, four otherwise)
+    if (gen_short((uint32_t)prm.max_value)) {
 #pragma unroll
-    for (int e = 0; e < M * D; e += 4) {
-      const U4 r = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), (uint32_t)(e >> 2), kStreamGenerate,
-                              prm.seed);
-      const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+      for (int e = 0; e < M * D; e += 8) {
+        const U4 r = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), (uint32_t)(e >> 3), kStreamGenerate, prm.seed);
+        uint32_t v[8];
+        gen_block_values(r, (uint32_t)prm.max_value, true, v);
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd)
-        if (e + qd < M * D) mine[e + qd] = (float)mulhi32(w[qd], (uint32_t)prm.max_value);
+        for (int qd = 0; qd < 8; ++qd)
+          if (e + qd < M * D) mine[e + qd] = (float)v[qd];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < M * D; e += 4) {
+        const U4 r = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), (uint32_t)(e >> 2), kStreamGenerate, prm.seed);
+        uint32_t v[8];
+        gen_block_values(r, (uint32_t)prm.max_value, false, v);
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+          if (e + qd < M * D) mine[e + qd] = (float)v[qd];
+      }
     }
   } else {
     fast_slab_commit<M, D>(slab, lds, ngames, lane);

@@ -149,12 +149,14 @@ __global__ __launch_bounds__(kWave) void generic_kernel(const Params prm) {
   if (prm.mode == kModeGenerate) {
     if (active) {
       const uint64_t gg = prm.game_offset + (uint64_t)g;
-      for (int e = 0; e < n; e += 4) {
-        const U4 r = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), (uint32_t)(e >> 2),
-                                kStreamGenerate, prm.seed);
-        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-        for (int q = 0; q < 4 && e + q < n; ++q)
-          p[e + q] = (T)mulhi32(w[q], (uint32_t)prm.max_value);
+      // (hk_common.h: eight elements per Philox block for small max_value, four otherwise)
+      const bool sh = gen_short((uint32_t)prm.max_value);
+      const int per = sh ? 8 : 4;
+      for (int e = 0; e < n; e += per) {
+        const U4 r = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), (uint32_t)(e / per), kStreamGenerate, prm.seed);
+        uint32_t v[8];
+        gen_block_values(r, (uint32_t)prm.max_value, sh, v);
+        for (int q = 0; q < per && e + q < n; ++q) p[e + q] = (T)v[q];
       }
       stages_game(p, m, d, c, -1, pad, prm.stages & ~HK_STAGE_SHIFT, prm.flags);
     }
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(kWave) void generic_kernel(const Params prm) {
   }
 
   // ---- kModeRollout: T fused steps, state never leaves LDS ---------------------------------
-  const uint64_t gg = prm.game_offset + (uint64_t)((prm.game_ids && active) ? (int64_t)prm.game_ids[g] : g);
+  const uint64_t gg = prm.game_offset + ((prm.game_ids && active) ? (uint64_t)(uint32_t)prm.game_ids[g] : (uint64_t)g);  // (ids: unsigned 32-bit)
   int np = active ? num_points(p, m, d) : 2;
   int length = (np < 2) ? 0 : -1;
   if (prm.count_ws) {

@@ -1,0 +1,363 @@
+// Four lanes per game, state generation: hk_generate_points on the four-lane data flow of hk_quad_kernel.h.
+//
+// generate_pts (hironaka/jax/util.py:385-392): randint[0, max_value) -> float32 -> Newton polytope -> [reposition] ->
+// [rescale].  The generator stream (DESIGN.md "Randomness"; hk_common.h: gen_block_values) is Philox4x32-10 keyed by the
+// seed with counter (game_lo, game_hi, block, kStreamGenerate): eight elements per block (16-bit draws) while max_value
+// is small, four otherwise.
+//
+// Rounds 1 - 3 ran this on hk::fast_kernel: ONE lane per game computes the game's M * D / 4 Philox blocks, scans its
+// image and walks the whole triangle of row pairs -- 21.5 us per 65 536 (20,3)-games, one wave per SIMD, longer than the
+// 19.4 us rollout it feeds.  Here a QUAD of lanes owns a game (16 games per wave, four waves per SIMD):
+//   * the Philox blocks of a game are dealt over its four lanes: block b goes to lane b & 3, its eight (or four) values as
+//     16-B LDS writes at their place in the game's staging image -- the concatenation of the blocks IS the game --, and
+//     lane j reads rows j, j + 4, ... back;
+//   * every row of a fresh game is live (the draws are non-negative), so a row's rank is its index: no scan, no
+//     compaction, rank of (slot s, lane j) = 4 s + j as qd_newton / qd_newton_two_level expect;
+//   * the stages run once, straight-line, for all R slots: the DPP pair test up to 8 slots per lane, the two-level test
+//     through the parked rows beyond ((50,4): 13 slots per lane);
+//   * every lane writes its own rows (or padding) to their places in the wave's image: no fill pass; one slab store.
+// The exactness guard has nothing to check here: the draws are finite and >= +0.  What the guard's other half covers --
+// a duplicate-fill value (-1.0 under JAX semantics, _jax_ops.py:65) different from the padding value -- and the sorted
+// output of the list semantics stay with the other kernels (quadgen_supported declines).
+#pragma once
+
+#include "hk_quad_kernel.h"
+
+namespace hk {
+
+template <int M, int D>
+struct QuadGenGeom {
+  using G = QuadGeom<M, D>;
+  static constexpr int R = G::R;
+  // Philox blocks per game: eight elements per block for small max_value, four otherwise (hk_common.h)
+  static constexpr int kBlocksShort = (M * D + 7) / 8, kBlocksLong = (M * D + 3) / 4;
+  // floats per game of the staging image: whole blocks, 16-B aligned
+  static constexpr int kStage = (kBlocksShort * 8 > kBlocksLong * 4) ? kBlocksShort * 8 : kBlocksLong * 4;
+  static constexpr int kRegion =  // floats per wave: staging and image alias
+      (kQuadGames * kStage > G::kImage) ? kQuadGames * kStage : G::kImage;
+  static_assert(G::kGameStride == G::N, "the parked rows of the pair loops lie in the game's part of the image");
+  static constexpr bool kTwoLevel = R > kQuadDppSlots && M <= 64;  // qd_newton_two_level's scratch: 128 B per game
+};
+
+// The rows of game `gg` in the four-lane layout: slot s of lane j = row 4 s + j; slots past the game's M rows are holes.
+// Block b is computed by lane b & 3 of the quad and written -- 32 or 16 bytes -- at its place in the game's staging image
+// (the concatenation of the blocks IS the game); lane j then reads rows j, j + 4, ....  `stage`: the wave's LDS region,
+// free again on return.
+template <int M, int D, int RD>
+__device__ __forceinline__ void qg_rows(float (&q)[RD], float* stage, uint64_t gg, uint64_t seed, uint32_t max_value,
+                                        int j, int gi) {
+  using GG = QuadGenGeom<M, D>;
+  constexpr int R = GG::R;
+  static_assert(RD == R * D, "slots per lane x dim");
+  float* mine = stage + gi * GG::kStage;
+  if (gen_short(max_value)) {  // (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < (GG::kBlocksShort + kQuad - 1) / kQuad; ++i) {
+      const int b = kQuad * i + j;
+      const U4 r = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), (uint32_t)b, kStreamGenerate, seed);
+      uint32_t v[8];
+      gen_block_values(r, max_value, true, v);
+      if ((kQuad * i + kQuad <= GG::kBlocksShort) || b < GG::kBlocksShort) {
+        *reinterpret_cast<vf4*>(mine + 8 * b) = vf4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        *reinterpret_cast<vf4*>(mine + 8 * b + 4) = vf4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < (GG::kBlocksLong + kQuad - 1) / kQuad; ++i) {
+      const int b = kQuad * i + j;
+      const U4 r = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), (uint32_t)b, kStreamGenerate, seed);
+      uint32_t v[8];
+      gen_block_values(r, max_value, false, v);
+      if ((kQuad * i + kQuad <= GG::kBlocksLong) || b < GG::kBlocksLong)
+        *reinterpret_cast<vf4*>(mine + 4 * b) = vf4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+  }
+  wave_lds_fence();
+#pragma unroll
+  for (int s = 0; s < R; ++s) {
+    const bool has = (kQuad * s + kQuad <= M) || kQuad * s + j < M;
+    const float* src = mine + (has ? kQuad * s + j : 0) * D;
+    if constexpr (D == 4) {
+      const vf4 v = *reinterpret_cast<const vf4*>(src);
+      q[s * D] = has ? v.x : INFINITY;
+      q[s * D + 1] = has ? v.y : INFINITY;
+      q[s * D + 2] = has ? v.z : INFINITY;
+      q[s * D + 3] = has ? v.w : INFINITY;
+    } else {
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const float v = src[k];
+        q[s * D + k] = has ? v : INFINITY;
+      }
+    }
+  }
+  wave_lds_fence();  // (the region becomes the output image)
+}
+
+// ---- the domination test of a FRESH game on packed rows (many slots per lane: (50,4)) ----------------------------------
+// A fresh draw below 127 fits seven bits, so a row of up to four coordinates is ONE dword with a guard bit above every
+// field, and "a <= b in every coordinate" is one subtraction: no field of (b | H) - a borrows iff every b_k >= a_k, i.e.
+// iff all guard bits H = 0x80808080 survive -- v_sub, v_and, v_cmp where the float test takes ten instructions on four
+// registers per row.  A hole is 0x7F7F7F7F: above every row, dominated by all of them, dominating none.
+//   level 0: every lane's row of least coordinate sum (v_sad_u8) is a "champion"; the quad's four champions (DPP) are
+//            tested against all slots -- strict domination only, so a champion never removes itself or its twins.
+//            Domination is transitive and the result is the set of minimal rows (of equal rows the one of lowest rank),
+//            so a row may go as soon as ANY row dominates it.  Of 50 uniform rows in dimension 4 about 20 survive (30 in
+//            the widest of a wave's 16 games; the own-slot triangles of qd_newton_two_level leave 29 / 36);
+//   level 1: the survivors are parked at their rank among the survivors (rank order = row order: it decides between equal
+//            rows), re-dealt four ways, and every lane tests its slots against ALL of them (one broadcast read per
+//            row): removed iff dominated by a different row, or by an equal one of lower rank.  The verdicts return
+//            through a byte per survivor.
+// `sc`: the game's LDS scratch, 16-B aligned, M + 4 dwords + M bytes.  Equal to _jax_ops.py:15-73 on integer rows; `reposition` commutes with
+// it there (a column's minimum over the survivors is its minimum over all rows: a row holding it can only be dominated by
+// a row that holds it too), so the caller subtracts the minima afterwards, on the survivors' floats.
+constexpr uint32_t kPackGuard = 0x80808080u, kPackHole = 0x7F7F7F7Fu;
+constexpr int kPackMaxValue = 127;  // draws are < max_value: at most 126
+
+// rows [4 (C - 1), 4 C) of the parked survivors against the lane's slots, for C = 1 .. NB2: against such a row, slot
+// s < C - 1 is the EARLIER row (it goes only if the row is below it and different), slot s > C - 1 the later one (an
+// equal row removes it too), slot C - 1 is decided per row.  The verdicts accumulate as lane masks in scalar registers
+// (ballots: no vector instruction; as a bool per slot the compiler packed them into bytes of vector registers, ~30
+// instructions per row).
+typedef uint32_t vu4 __attribute__((ext_vector_type(4)));
+
+template <int NB2, int C>
+struct QgPackedSeg {
+  // `cur`: the segment's four rows (one 16-B read); the next segment's are requested before this one's tests.  Slot by
+  // slot: the four rows' verdicts on a slot meet in scalar lane masks and are folded into the slot's counter at once
+  // (one vector instruction per slot and segment; a lane mask per slot kept over the whole level overflows the scalar
+  // registers: 2 000 spills in the build that tried).
+  static __device__ __forceinline__ void run(const uint32_t (&w2)[NB2], const uint32_t (&g2)[NB2], uint32_t (&cnt)[NB2],
+                                             const uint32_t* sv, int np1, int rows, int j, vu4 cur) {
+    constexpr int r0 = kQuad * (C - 1);
+    if (rows <= r0) return;  // (wave-uniform)
+    vu4 nxt = cur;
+    if constexpr (C < NB2) nxt = *reinterpret_cast<const vu4*>(sv + kQuad * C);
+    uint32_t c[kQuad];
+#pragma unroll
+    for (int rr = 0; rr < kQuad; ++rr) c[rr] = (r0 + rr < np1) ? cur[rr] : kPackHole;  // (past np1: holes, dominating nothing)
+#pragma unroll
+    for (int s = 0; s < NB2; ++s) {
+      bool hit = false;
+#pragma unroll
+      for (int rr = 0; rr < kQuad; ++rr) {
+        const bool dom = ((g2[s] - c[rr]) & kPackGuard) == kPackGuard;  // row <= my slot s, coordinate by coordinate
+        if (s > C - 1) hit |= dom;                                      // my slot is the later row: equal rows count
+        else if (s < C - 1) hit |= dom & (w2[s] != c[rr]);              // ... the earlier row: different rows only
+        else hit |= dom & ((w2[s] != c[rr]) | (rr < j));                // ... decided by the ranks r0 + rr and r0 + j
+      }
+      cnt[s] += hit ? 1u : 0u;
+    }
+    if constexpr (C < NB2) QgPackedSeg<NB2, C + 1>::run(w2, g2, cnt, sv, np1, rows, j, nxt);
+  }
+};
+
+template <int NB2>
+__device__ __forceinline__ void qg_packed_level1(const uint32_t* sv, uint8_t* vd, int np1, int rows, int j, int lane) {
+  uint32_t w2[NB2], g2[NB2], cnt[NB2];
+  const vu4 first = *reinterpret_cast<const vu4*>(sv);
+#pragma unroll
+  for (int s = 0; s < NB2; ++s) {
+    const int r = kQuad * s + j;
+    const uint32_t v = sv[r < rows ? r : 0];
+    w2[s] = (r < np1) ? v : kPackHole;
+    g2[s] = w2[s] | kPackGuard;
+    cnt[s] = 0u;
+  }
+  QgPackedSeg<NB2, 1>::run(w2, g2, cnt, sv, np1, rows, j, first);  // (rows: wave-uniform, >= every game's np1)
+#pragma unroll
+  for (int s = 0; s < NB2; ++s) {
+    const int r = kQuad * s + j;
+    if (r < np1) vd[r] = cnt[s] ? (uint8_t)1 : (uint8_t)0;
+  }
+}
+
+template <int M, int D, int R>
+__device__ __forceinline__ void qg_newton_packed(float (&q)[R * D], uint32_t* sc, int j, int lane) {
+  static_assert(D <= 4, "a row travels as four 7-bit fields");
+  uint32_t w[R];
+#pragma unroll
+  for (int s = 0; s < R; ++s) {
+    uint32_t v = (uint32_t)q[s * D];
+#pragma unroll
+    for (int k = 1; k < D; ++k) v |= (uint32_t)q[s * D + k] << (8 * k);
+    w[s] = (q[s * D] < INFINITY) ? v : kPackHole;
+  }
+  // level 0: the quad's four champions against every slot
+  {
+    uint32_t bs = __builtin_amdgcn_sad_u8(w[0], 0u, 0u), bw = w[0];
+#pragma unroll
+    for (int s = 1; s < R; ++s) {
+      const uint32_t ss = __builtin_amdgcn_sad_u8(w[s], 0u, 0u);
+      const bool lt = ss < bs;
+      bs = lt ? ss : bs;
+      bw = lt ? w[s] : bw;
+    }
+    const uint32_t c0 = bw, c1 = (uint32_t)qperm_i<kQuadUp1>((int)bw), c2 = (uint32_t)qperm_i<kQuadUp2>((int)bw),
+                   c3 = (uint32_t)qperm_i<kQuadUp3>((int)bw);
+#pragma unroll
+    for (int s = 0; s < R; ++s) {
+      const uint32_t g = w[s] | kPackGuard;
+      const bool r0 = (((g - c0) & kPackGuard) == kPackGuard) & (w[s] != c0);
+      const bool r1 = (((g - c1) & kPackGuard) == kPackGuard) & (w[s] != c1);
+      const bool r2 = (((g - c2) & kPackGuard) == kPackGuard) & (w[s] != c2);
+      const bool r3 = (((g - c3) & kPackGuard) == kPackGuard) & (w[s] != c3);
+      w[s] = (r0 | r1 | r2 | r3) ? kPackHole : w[s];
+    }
+  }
+  // the survivors to their ranks (popcounts of the four lanes' masks, hk_quadroll_kernel.h: qr_redeal)
+  uint32_t lm = 0;
+#pragma unroll
+  for (int s = 0; s < R; ++s) lm |= (w[s] != kPackHole) ? (1u << s) : 0u;
+  const int np1 = q_sum(__popc(lm));
+  int s1 = R;  // slots per lane at level 1: the wave-uniform maximum of ceil(np1 / 4)
+#pragma nounroll
+  while (s1 > 1 && !__any(np1 > kQuad * (s1 - 1))) --s1;
+  const uint32_t l1 = (uint32_t)qperm_i<kQuadUp1>((int)lm), l2 = (uint32_t)qperm_i<kQuadUp2>((int)lm),
+                 l3 = (uint32_t)qperm_i<kQuadUp3>((int)lm);
+  const bool b1 = ((j + 1) & 3) < j, b2 = ((j + 2) & 3) < j, b3 = ((j + 3) & 3) < j;
+  uint8_t* vd = reinterpret_cast<uint8_t*>(sc + M + 4);  // (segment reads run up to 3 dwords past the M rows)
+  int rk[R];
+#pragma unroll
+  for (int s = 0; s < R; ++s) {
+    const uint32_t below = (1u << s) - 1u, at = 1u << s;
+    rk[s] = __popc(lm & below) + __popc(l1 & (below | (b1 ? at : 0u))) + __popc(l2 & (below | (b2 ? at : 0u))) +
+            __popc(l3 & (below | (b3 ? at : 0u)));
+    if ((lm >> s) & 1u) sc[rk[s]] = w[s];
+  }
+  wave_lds_fence();
+  const int rows = (kQuad * s1 < M) ? kQuad * s1 : M;
+  // (buckets of slots per lane; 50 uniform rows in dimension 4: the widest of a wave's 16 games keeps 26 - 36 rows after
+  // level 0, 7 - 9 slots per lane)
+  if (s1 <= 2) qg_packed_level1<(R < 2 ? R : 2)>(sc, vd, np1, rows, j, lane);
+  else if (s1 <= 4) qg_packed_level1<(R < 4 ? R : 4)>(sc, vd, np1, rows, j, lane);
+  else if (s1 <= 6) qg_packed_level1<(R < 6 ? R : 6)>(sc, vd, np1, rows, j, lane);
+  else if (s1 <= 7) qg_packed_level1<(R < 7 ? R : 7)>(sc, vd, np1, rows, j, lane);
+  else if (s1 <= 8) qg_packed_level1<(R < 8 ? R : 8)>(sc, vd, np1, rows, j, lane);
+  else if (s1 <= 9) qg_packed_level1<(R < 9 ? R : 9)>(sc, vd, np1, rows, j, lane);
+  else if (s1 <= 10) qg_packed_level1<(R < 10 ? R : 10)>(sc, vd, np1, rows, j, lane);
+  else qg_packed_level1<R>(sc, vd, np1, rows, j, lane);
+  wave_lds_fence();
+#pragma unroll
+  for (int s = 0; s < R; ++s) {
+    const bool kept = ((lm >> s) & 1u) && vd[((lm >> s) & 1u) ? rk[s] : 0] == 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[s * D + k] = kept ? q[s * D + k] : INFINITY;
+  }
+  wave_lds_fence();  // (the scratch is the game's image again)
+}
+
+// the generator's stages on all R slots (every row live: ranks = row indices); returns the GAME's number of live rows
+template <int M, int D, int RD>
+__device__ __forceinline__ int qg_stages(float (&q)[RD], int j, unsigned flags, unsigned stages, float* cmine,
+                                         uint8_t* tsc, int max_value, int lane) {
+  using G = QuadGeom<M, D>;
+  constexpr int R = G::R;
+  static_assert(RD == R * D, "slots per lane x dim");
+  // many slots per lane, small draws: the Newton stage on packed rows, the minima subtracted afterwards
+  const bool packed = R > kQuadDppSlots && D <= 4 && (stages & HK_STAGE_NEWTON) && max_value <= kPackMaxValue;
+  if constexpr (R > kQuadDppSlots && D <= 4) {
+    if (packed) qg_newton_packed<M, D, R>(q, reinterpret_cast<uint32_t*>(cmine), j, lane);
+  }
+  if (stages & HK_STAGE_REPOSITION) qd_reposition<R, D, R>(q, flags);
+  if ((stages & HK_STAGE_NEWTON) && !packed) {
+    if constexpr (R > kQuadDppSlots) {
+      if constexpr (QuadGenGeom<M, D>::kTwoLevel) qd_newton_two_level<M, G::CW, R, D, R>(q, cmine, tsc, j, M);
+      else qd_newton_lds<M, G::CW, R, D, R>(q, cmine, j, M);
+    } else {
+      qd_newton<R, D, R>(q, j);
+    }
+  }
+  if (stages & HK_STAGE_RESCALE) qd_rescale<R, D, R>(q, flags);
+  int n = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) n += (q[r * D] < INFINITY) ? 1 : 0;
+  return q_sum(n);
+}
+
+template <int M, int D, int WPB>
+__global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void quadgen_kernel(float* out0, int batch0,
+                                                                                              const Params prm) {
+  using G = QuadGeom<M, D>;
+  using GG = QuadGenGeom<M, D>;
+  constexpr int R = G::R;
+  __shared__ __align__(16) float lds_all[WPB * GG::kRegion];
+  __shared__ __align__(16) uint8_t tsc_all[GG::kTwoLevel ? WPB * kQuadGames * 128 : 16];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & (kWave - 1);
+  float* region = lds_all + wave * GG::kRegion;
+  const int j = lane & 3, gi = lane >> 2;
+  const int64_t g0 = ((int64_t)blockIdx.x * WPB + wave) * kQuadGames;
+  const int64_t left = (int64_t)batch0 - g0;
+  if (left <= 0) return;  // (waves of a workgroup never meet at a barrier)
+  const int ngames = (int)(left < kQuadGames ? left : kQuadGames);
+  const uint64_t gg = prm.game_offset + (uint64_t)(g0 + gi);  // (quads past the batch draw games nobody stores)
+  float q[R * D];
+  qg_rows<M, D>(q, region, gg, prm.seed, (uint32_t)prm.max_value, j, gi);
+  float* mine = region + gi * G::N;
+  uint8_t* tsc = GG::kTwoLevel ? tsc_all + (wave * kQuadGames + gi) * 128 : nullptr;
+  // (the parked rows of the big games' pair loops: the game's part of the region -- G::kGameStride == N there)
+  (void)qg_stages<M, D>(q, j, prm.flags, prm.stages, region + gi * G::kGameStride, tsc, prm.max_value, lane);
+  const float pad = prm.pad_f32;
+#pragma unroll
+  for (int s = 0; s < R; ++s) {
+    if ((kQuad * s + kQuad <= M) || kQuad * s + j < M) {
+      const bool removed = !(q[s * D] < INFINITY);
+      float* dst = mine + (kQuad * s + j) * D;
+      if constexpr (D == 4) {
+        *reinterpret_cast<vf4*>(dst) = vf4{removed ? pad : q[s * D], removed ? pad : q[s * D + 1],
+                                           removed ? pad : q[s * D + 2], removed ? pad : q[s * D + 3]};
+      } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) dst[k] = removed ? pad : q[s * D + k];
+      }
+    }
+  }
+  wave_lds_fence();
+  quad_slab_store<M, D>(region, out0 + g0 * G::N, ngames, lane);
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+template <int M, int D>
+int launch_quadgen_t(Params prm, hipStream_t stream) {
+  constexpr int WPB = quad_waves_per_block<M, D>();
+  const int64_t waves = ((int64_t)prm.batch + kQuadGames - 1) / kQuadGames;
+  const unsigned grid = (unsigned)((waves + WPB - 1) / WPB);
+  prm.pad_f32 = (float)prm.pad;
+  launch_prepare();
+  hipLaunchKernelGGL((quadgen_kernel<M, D, WPB>), dim3(grid), dim3(kWave * WPB), 0, stream, (float*)prm.out, prm.batch,
+                     prm);
+  return launch_status();
+}
+
+// hk_generate_points requests this kernel serves: float32, contiguous W-aligned records, in-place order, a duplicate
+// fill equal to the padding value (the other kernels' exactness guard sends anything else down the generic routines)
+inline bool quadgen_supported(const Params& prm, int dtype) {
+  if (dtype != HK_F32 || prm.mode != kModeGenerate) return false;
+  if (prm.flags & (HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_TEAM | HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES))
+    return false;
+  if ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)) return false;
+  if ((prm.flags & HK_SEM_MASK) == HK_SEM_JAX && (prm.stages & HK_STAGE_NEWTON) && (float)prm.pad != -1.0f) return false;
+  if (!((float)prm.pad < 0.0f)) return false;  // (a removed row must read as padding)
+  if (prm.out_stride != (int64_t)prm.m * prm.d) return false;
+#define HK_X(M_, D_) \
+  if (prm.m == M_ && prm.d == D_) return reinterpret_cast<uintptr_t>(prm.out) % (QuadGeom<M_, D_>::W * 4) == 0;
+  HK_QUAD_SPECS(HK_X)
+#undef HK_X
+  return false;
+}
+
+#ifndef HK_SPEC_TU
+#define HK_X(M_, D_) extern template int launch_quadgen_t<M_, D_>(Params, hipStream_t);
+HK_QUAD_SPECS(HK_X)
+#undef HK_X
+
+inline int launch_quadgen(const Params& prm, hipStream_t stream) {
+#define HK_X(M_, D_) if (prm.m == M_ && prm.d == D_) return launch_quadgen_t<M_, D_>(prm, stream);
+  HK_QUAD_SPECS(HK_X)
+#undef HK_X
+  return HK_ERR_UNSUPPORTED;
+}
+#endif
+
+}  // namespace hk

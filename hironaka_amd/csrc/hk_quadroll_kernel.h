@@ -692,8 +692,7 @@ inline bool quadroll_request_ok(const Params& prm) {
   if ((prm.stages & HK_STAGE_NEWTON) &&
       ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)))
     return false;
-  if (prm.flags & (HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_TEAM | HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES |
-                   HK_FLAG_FORCE_POOL))
+  if (prm.flags & (HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_TEAM | HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES))
     return false;
   return true;
 }
@@ -742,7 +741,7 @@ inline bool quadroll_supported(const Params& prm, int dtype) {
 
 // where this kernel is the default: the shapes without a two-lane kernel ((50,4): hk::team_kernel's rollouts before)
 // ... and, on the small shapes, batches of up to two of its waves per SIMD (32 768 games on an MI355X): measured
-// (scripts/probe_pool.py, (20,3)): 14.0 / 15.0 / 17.4 us per 20-step episode at 4 096 / 16 384 / 32 768 games against
+// (scripts/probe_rollout_families.py, (20,3)): 14.0 / 15.0 / 17.4 us per 20-step episode at 4 096 / 16 384 / 32 768 games against
 // 16.9 / 18.3 / 18.8 on two lanes per game, 24.5 against 22.2 at 65 536
 // Recording rollouts: at every size (scripts/probe_records.py, (20,3), per 20-step episode incl. the counter reduce:
 // 39.8 against 48.6 us with the small records and 69.5 against 82.1 us with the observations at 65 536 games, 90.6 / 240

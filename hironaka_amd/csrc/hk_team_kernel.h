@@ -420,7 +420,7 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
   const bool leader = active && tl == 0;
   const int64_t g = g0 + tg;
   const uint64_t gg =
-      prm.game_offset + (uint64_t)((prm.mode == kModeRollout && prm.game_ids && active) ? (int64_t)prm.game_ids[g] : g);
+      prm.game_offset + ((prm.mode == kModeRollout && prm.game_ids && active) ? (uint64_t)(uint32_t)prm.game_ids[g] : (uint64_t)g);
   float* mine = lds + tg * S;
   const float pad = (float)prm.pad;
   const unsigned flags = prm.flags;
@@ -444,14 +444,17 @@ __global__ __launch_bounds__(kWave, (D <= 4 ? 3 : 2)) void team_kernel(const Par
 
   // ---- 1. the image --------------------------------------------------------------------------------
   if (MODE == kModeGenerate) {
-    if (active)
-      for (int e = tl * 4; e < n_el; e += 4 * kTeam) {
-        const U4 r = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), (uint32_t)(e >> 2), kStreamGenerate,
-                                prm.seed);
-        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-        for (int qd = 0; qd < 4 && e + qd < n_el; ++qd)
-          mine[e + qd] = (float)mulhi32(w[qd], (uint32_t)prm.max_value);
+    if (active) {
+      // (hk_common.h: eight elements per Philox block for small max_value, four otherwise; block b -> lane b % 4)
+      const bool sh = gen_short((uint32_t)prm.max_value);
+      const int per = sh ? 8 : 4;
+      for (int e = tl * per; e < n_el; e += per * kTeam) {
+        const U4 r = philox4x32((uint32_t)gg, (uint32_t)(gg >> 32), (uint32_t)(e / per), kStreamGenerate, prm.seed);
+        uint32_t v[8];
+        gen_block_values(r, (uint32_t)prm.max_value, sh, v);
+        for (int qd = 0; qd < per && e + qd < n_el; ++qd) mine[e + qd] = (float)v[qd];
       }
+    }
   } else {
     rows_copy_slab<true>(lds, const_cast<float*>((const float*)prm.in), prm.in_stride, n_el, S, g0, ngames, lane,
                         vec_in);

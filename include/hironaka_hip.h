@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define HK_ABI_VERSION 3 /* 2: + HK_AXIS_MASKED_LOGITS, hk_step_features, hk_rollout_values, hk_search_expand_* / _masked_argmax / _mask_logits; 3: + hk_rollout_desc.game_ids */
+#define HK_ABI_VERSION 4 /* 2: + HK_AXIS_MASKED_LOGITS, hk_step_features, hk_rollout_values, hk_search_expand_* / _masked_argmax / _mask_logits; 3: + hk_rollout_desc.game_ids (and the policy stream of dim <= 8 became four steps per Philox block with 16-bit draws: seeds are not comparable with ABI 2); 4: + hk_rollout_desc.gen_max_value / gen_stages / gen_seed / episodes (initial states drawn inside the launch, `points` may be NULL), - HK_FLAG_FORCE_POOL */
 
 /* ---- status codes -------------------------------------------------------------------- */
 #define HK_OK 0
@@ -115,9 +115,7 @@ extern "C" {
 #define HK_FLAG_FORCE_TWO_LANES 512u    /* testing / tuning: two lanes per game (hk::duo_kernel) at any batch size */
 #define HK_FLAG_FORCE_FOUR_LANES 1024u  /* testing / tuning: four lanes per game (hk::quad_kernel) for every hk_step
                                          * it can serve, at any batch size                                       */
-#define HK_FLAG_FORCE_POOL 2048u        /* testing / tuning: hk_rollout on the pool kernel (hk::pool_kernel: 256 games per
-                                         * workgroup, live games re-dealt to the waves between steps) for every
-                                         * rollout it can serve, at any batch size                                  */
+/* (2048u: HK_FLAG_FORCE_POOL of ABI 3 -- the block-level re-deal experiment left the library in ABI 4; reserved) */
 #define HK_FLAG_DEFER_COUNTS 128u       /* hk_rollout: leave the finished-game counts as partial
                                            sums in `workspace` (they accumulate over launches);
                                            hk_rollout_reduce_counts adds them to done_count     */
@@ -207,7 +205,24 @@ typedef struct hk_rollout_desc {
                               whose games were re-ordered (binned by live rows at generate time so
                               that a wave holds games of one size) rolls out exactly as the
                               original order would, game by game.  The reference's batches carry
-                              no order (jax/util.py:385-392 draws them at random).              */
+                              no order (jax/util.py:385-392 draws them at random).  Non-negative
+                              (read as unsigned 32-bit).                                         */
+  /* ---- ABI 4: the whole loop of compute_rho (jax_trainer.py:502-555) in one launch.  The reference draws a
+   * fresh batch per loop (jax/util.py:385-392) and reads nothing back but a histogram; with gen_max_value > 0 the
+   * initial state of game g is what hk_generate_points(max_value = gen_max_value, seed = gen_seed, game_offset + g
+   * [or + game_ids[g]], stages = gen_stages, padding_value, the semantics bits of flags) would have written --
+   * drawn inside the launch, never stored.  points_in must then be NULL, and `points` MAY be NULL ("counts only":
+   * no final state is written either; done_count / game_length_out are the products).                          */
+  int32_t gen_max_value; /* 0: the initial state comes from memory (points_in / points)                          */
+  uint32_t gen_stages;   /* HK_STAGE_NEWTON | HK_STAGE_REPOSITION | HK_STAGE_RESCALE of the generator            */
+  uint64_t gen_seed;
+  int32_t episodes;      /* 0 or 1: one episode.  E > 1: E independent episodes back to back inside the launch
+                            (a wave starts its next episode when its own games are finished: no launch boundary,
+                            nothing waits for the slowest wave) -- episode e starts from the initial state again
+                            (points_in, or generated with gen_seed + e) and plays with seed + e; done_count
+                            accumulates over the episodes; `points` and game_length_out, if given, receive the LAST
+                            episode's; needs points_in or gen_max_value, no per-step records                   */
+  int32_t reserved_;     /* 0                                                                                    */
 } hk_rollout_desc;
 
 /* ---- library ---------------------------------------------------------------------------- */

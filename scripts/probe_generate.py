@@ -1,5 +1,6 @@
-"""Dev probe: hk_generate_points (randint -> newton -> reposition, jax/util.py:385-392) per shape, next to the same
-result from the raw generator + the stage operators on the step kernels."""
+"""Dev probe: hk_generate_points (randint -> newton -> reposition, jax/util.py:385-392) per shape and kernel family
+(default = hk::quadgen_kernel where it exists; one lane per game / team forced by flag), the raw draws alone, and the
+fraction of the HBM peak the writes reach."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,20 +8,20 @@ from hironaka_amd import ops, _abi as A
 from probe_records import timed
 
 if __name__ == "__main__":
-    for b, m, d in ((65536, 20, 3), (8192, 20, 3), (262144, 50, 4), (65536, 20, 4)):
-        def gen():
+    for b, m, d in ((65536, 20, 3), (8192, 20, 3), (524288, 20, 3), (65536, 10, 3), (65536, 20, 4), (262144, 50, 4)):
+        out = torch.empty((b, m, d), device="cuda")
+        line = f"({m},{d}) b={b}:"
+        ref = None
+        for name, fl in (("default", 0), ("one", A.HK_FLAG_FORCE_ONE_LANE), ("team", A.HK_FLAG_FORCE_TEAM)):
+            def gen():
+                for i in range(3):
+                    ops.generate_points(b, m, d, 20, seed=42 + i, flags=fl, out=out)
+            t = timed(gen) / 3 * 1e6
+            got = ops.generate_points(b, m, d, 20, seed=44, flags=fl)
+            ref = got if ref is None else ref
+            line += f"  {name} {t:7.1f} us ({b * m * d * 4 / t / 8e6:.2f} of HBM peak{'' if torch.equal(ref, got) else ' DIFFERENT'})"
+        def raw():
             for i in range(3):
-                ops.generate_points(b, m, d, 20, seed=42 + i)
-        t_gen = timed(gen) / 3 * 1e6
-        raw = ops.generate_points(b, m, d, 20, seed=42, newton=False, reposition=False)
-        out = torch.empty_like(raw)
-        def two():
-            for i in range(3):
-                r = ops.generate_points(b, m, d, 20, seed=42 + i, newton=False, reposition=False)
-                ops.step(r, stages=A.HK_STAGE_NEWTON | A.HK_STAGE_REPOSITION, out=out)
-        try:
-            t_two = timed(two) / 3 * 1e6
-            same = torch.equal(out, ops.generate_points(b, m, d, 20, seed=44))
-        except Exception as e:
-            t_two, same = float("nan"), str(e)[:60]
-        print(f"({m},{d}) b={b}: generate_points {t_gen:8.1f} us   raw + newton + reposition {t_two:8.1f} us  (equal: {same})", flush=True)
+                ops.generate_points(b, m, d, 20, seed=42 + i, newton=False, reposition=False, out=out)
+        line += f"  raw draws {timed(raw) / 3 * 1e6:7.1f} us"
+        print(line, flush=True)

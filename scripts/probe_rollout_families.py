@@ -1,4 +1,4 @@
-"""Fused 20-step rollouts: hk::pool_kernel against the fixed-deal kernels (hk::duo_kernel / hk::fast_kernel) over batch
+"""Fused 20-step rollouts: the rollout kernel families (hk::duo_kernel / hk::fast_kernel) over batch
 sizes; hipGraph of 10 episodes, median of 8 event segments."""
 import sys, os, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -35,7 +35,7 @@ for m, d in shapes:
         state = torch.empty_like(fresh)
         ws = ops.rollout_workspace(b, 20, (m, d))
         out = {}
-        for name, fl in (("default", 0), ("pool", A.HK_FLAG_FORCE_POOL), ("two", A.HK_FLAG_FORCE_TWO_LANES), ("quad", A.HK_FLAG_FORCE_FOUR_LANES),
+        for name, fl in (("default", 0), ("two", A.HK_FLAG_FORCE_TWO_LANES), ("quad", A.HK_FLAG_FORCE_FOUR_LANES),
                          ("one", A.HK_FLAG_FORCE_ONE_LANE)):
             def ep():
                 for _ in range(10):

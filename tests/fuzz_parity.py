@@ -79,7 +79,7 @@ def one_case(rng):
     sem = ["jax", "torch", "list"][rng.integers(0, 3)]
     pad = float(rng.choice([-1.0, -1.0, -1.0, -1e-8, -2.5]))
     force = int(rng.choice([0, 0, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_TWO_LANES, A.HK_FLAG_FORCE_FOUR_LANES,
-                           A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC, A.HK_FLAG_FORCE_POOL]))
+                           A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC]))
     noop, ign = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     if rng.integers(0, 4) == 0:  # the flag sets of the compiled rollout configurations
         noop = ign = (sem == "torch")

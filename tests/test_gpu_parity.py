@@ -398,6 +398,31 @@ def test_generate_matches_oracle(spec, force_generic):
     assert np.array_equal(host(raw), NO.random_ints(300, m, d, 7, 1).astype(np.float32))
 
 
+@pytest.mark.parametrize("spec", [(10, 3), (20, 3), (20, 4), (50, 4)])
+def test_generate_families_match_oracle(spec):
+    """hk_generate_points on the shapes with a four-lane generator (hk::quadgen_kernel, the default) against the oracle
+    and against the one-lane / team / generic kernels forced by flag: batches that leave a wave partly empty, one
+    game, value ranges that make many duplicate rows (max_value 2) and none (max_value 1000), every stage subset, torch
+    semantics, a game offset beyond 2^32, and a padding value the four-lane kernel declines under JAX semantics
+    (_jax_ops.py:65 fills duplicates with -1.0 whatever the padding is: the exact generic routines take it)."""
+    m, d = spec
+    N, R, S = A.HK_STAGE_NEWTON, A.HK_STAGE_REPOSITION, A.HK_STAGE_RESCALE
+    families = (0, A.HK_FLAG_FORCE_FOUR_LANES, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC)
+    cases = [dict(b=b, mv=20, st=N | R, off=3, pad=-1.0, sem="jax") for b in (1, 15, 16, 17, 63, 65, 300)]
+    cases += [dict(b=200, mv=mv, st=N | R, off=0, pad=-1.0, sem="jax") for mv in (1, 2, 3, 1000, 2 ** 31 - 1)]
+    cases += [dict(b=130, mv=20, st=st, off=(1 << 33) + 5, pad=-1.0, sem="jax") for st in (0, N, R, S, N | S, N | R | S)]
+    cases += [dict(b=130, mv=20, st=st, off=7, pad=pad, sem="torch") for st in (N, N | R | S) for pad in (-1.0, -2.5)]
+    cases += [dict(b=130, mv=20, st=N | R, off=7, pad=-2.5, sem="jax")]
+    for c in cases:
+        fo = CO.flags_of(sem=c["sem"])
+        want = CO.generate_points(c["b"], m, d, c["mv"], 9, c["off"], stages=c["st"], padding_value=c["pad"], flags=fo)
+        for fam in families:
+            got = ops.generate_points(c["b"], m, d, c["mv"], seed=9, game_offset=c["off"], newton=bool(c["st"] & N),
+                                      reposition=bool(c["st"] & R), rescale=bool(c["st"] & S), padding_value=c["pad"],
+                                      flags=ops.make_flags(c["sem"]) | fam)
+            assert np.array_equal(host(got), want), (c, fam)
+
+
 @pytest.mark.parametrize("spec,force_generic", [((20, 3), False), ((20, 3), True), ((10, 3), False), ((8, 4), False),
                                                 ((6, 5), True), ((50, 4), False), ((7, 3), False), ((6, 5), False)])
 def test_rollout_matches_oracle(spec, force_generic):
@@ -497,8 +522,7 @@ def test_tiny_batches_and_degenerate_episodes(spec):
         for T in (0, 1, 25):
             for hp in (A.HK_HOST_RANDOM, A.HK_HOST_ZEILLINGER):
                 want_p, want = CO.rollout(p0, T, 5, step_offset=2, host_policy=hp, agent_policy=A.HK_AGENT_RANDOM, game_ids=ids)
-                for fl in (0, A.HK_FLAG_FORCE_TWO_LANES, A.HK_FLAG_FORCE_FOUR_LANES, A.HK_FLAG_FORCE_ONE_LANE,
-                           A.HK_FLAG_FORCE_POOL):
+                for fl in (0, A.HK_FLAG_FORCE_TWO_LANES, A.HK_FLAG_FORCE_FOUR_LANES, A.HK_FLAG_FORCE_ONE_LANE):
                     if m > 32 and fl not in (0, A.HK_FLAG_FORCE_FOUR_LANES):
                         continue
                     for rec in (("game_length",), small, ("obs",) + small):
@@ -538,8 +562,8 @@ def test_long_episodes_match_oracle(spec):
 def test_reordered_batch_with_game_ids_rolls_out_like_the_original(spec):
     """`hk_rollout_desc.game_ids` (round 3): a batch binned by live rows (`ops.bin_by_live_rows`) with the permutation as
     game ids gives, game by game, what the original order gives -- against the oracle with the same ids, and as the
-    permutation of the plain run; every family (four lanes, two lanes, one lane, team, generic; the pool kernel steps
-    aside), records included."""
+    permutation of the plain run; every family (four lanes, two lanes, one lane, team, generic),
+    records included."""
     m, d = spec
     p0 = CO.generate_points(32 * 9 + 5, m, d, 20, 21)
     P0 = dev(p0.copy())
@@ -590,8 +614,8 @@ def test_compiled_rollout_configurations_match_oracle(spec):
         for T in (1, 20):
             want_p, want = CO.rollout(p0, T, 31, game_offset=5, host_policy=A.HK_HOST_RANDOM, agent_policy=ap,
                                       stages=stages, flags=flags_o, record=False)
-            # hk::duo_kernel / hk::fast_kernel / hk::pool_kernel (where they exist; elsewhere the flags change nothing)
-            for lanes in (0, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_POOL, A.HK_FLAG_FORCE_FOUR_LANES):
+            # hk::duo_kernel / hk::fast_kernel / hk::quadroll_kernel (where they exist; elsewhere the flags change nothing)
+            for lanes in (0, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_TWO_LANES, A.HK_FLAG_FORCE_FOUR_LANES):
                 P = dev(p0.copy())
                 got = ops.rollout(P, T, 31, game_offset=5, host_policy=A.HK_HOST_RANDOM, agent_policy=ap,
                                   stages=stages, flags=flags_p | lanes, record=("game_length",))
@@ -600,17 +624,17 @@ def test_compiled_rollout_configurations_match_oracle(spec):
                 assert np.array_equal(host(got["game_length"]), want["game_length"]), (flags_p, T, lanes)
 
 
-@pytest.mark.parametrize("family,spec", [("pool", s) for s in ((20, 3), (10, 3), (5, 3), (16, 3), (8, 4), (20, 4))] +
+@pytest.mark.parametrize("family,spec", [("two", s) for s in ((20, 3), (10, 3), (5, 3), (16, 3), (8, 4), (20, 4))] +
                          [("quad", s) for s in ((20, 3), (10, 3), (20, 4), (50, 4))])
 def test_forced_rollout_families_match_oracle(family, spec):
-    """hk::pool_kernel (256 games per workgroup, live games re-dealt to the waves between rounds of steps) and
-    hk::quadroll_kernel (four lanes per game, decoded action windows of 24 steps) against the oracle: episode lengths
+    """hk::duo_kernel (two lanes per game) and hk::quadroll_kernel (four lanes per game), both with decoded action
+    windows of 24 steps, forced at every batch size, against the oracle: episode lengths
     on both sides of every round / window boundary, a step offset that is not a multiple of a Philox block, batches
     that leave waves / workgroups partly or wholly empty, the run-time configured variant (other policies, rescale, no
     reposition), a padding value that sends a workgroup down the exact generic path, and non-canonical games in one
     workgroup only"""
     m, d = spec
-    force = A.HK_FLAG_FORCE_POOL if family == "pool" else A.HK_FLAG_FORCE_FOUR_LANES
+    force = A.HK_FLAG_FORCE_TWO_LANES if family == "two" else A.HK_FLAG_FORCE_FOUR_LANES
     stages = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON
     torch_flags = ops.make_flags("torch", noop_if_invalid=True, ignore_ended=True)
     torch_flags_o = CO.flags_of(sem="torch", noop_if_invalid=True, ignore_ended=True)
@@ -646,29 +670,6 @@ def test_forced_rollout_families_match_oracle(family, spec):
         assert np.array_equal(host(P), want_p), c
         assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"]), c
         assert np.array_equal(host(got["game_length"]), want["game_length"]), c
-
-
-def test_pool_equals_fixed_deal_at_baseline_size():
-    """BASELINE configs[1] at size: the pool kernel and the two-lane kernel leave identical states, finished-game
-    histograms and game lengths (with and without a separate initial state), and deferred counts of launches of both
-    families meet in one workspace"""
-    b = 65536
-    fresh = ops.generate_points(b, 20, 3, 20, seed=42)
-    A1, A2 = torch.empty_like(fresh), torch.empty_like(fresh)
-    r1 = ops.rollout(A1, 20, 7, initial=fresh, flags=A.HK_FLAG_FORCE_TWO_LANES, record=("game_length",))
-    r2 = ops.rollout(A2, 20, 7, initial=fresh, flags=A.HK_FLAG_FORCE_POOL, record=("game_length",))
-    assert torch.equal(A1, A2)
-    assert torch.equal(r1["done_count"], r2["done_count"])
-    assert torch.equal(r1["game_length"], r2["game_length"])
-    B2 = fresh.clone()
-    ops.rollout(B2, 20, 7, flags=A.HK_FLAG_FORCE_POOL)
-    assert torch.equal(A1, B2)
-    ws = ops.rollout_workspace(b, 20, (20, 3))
-    dc = torch.zeros(21, dtype=torch.int64, device="cuda")
-    ops.rollout(A1, 20, 7, initial=fresh, flags=A.HK_FLAG_FORCE_TWO_LANES, defer_counts=True, workspace=ws)
-    ops.rollout(A2, 20, 7, initial=fresh, flags=A.HK_FLAG_FORCE_POOL, defer_counts=True, workspace=ws)
-    ops.reduce_counts(ws, dc, b, 20, (20, 3))
-    assert torch.equal(dc, 2 * r1["done_count"].to(torch.int64))
 
 
 def test_rollout_equals_stepwise_launches():
