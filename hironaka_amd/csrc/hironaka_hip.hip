@@ -379,20 +379,27 @@ static int params_from_rollout(const hk_rollout_desc* r, Params& prm) {
   if (!r) return HK_ERR_NULL;
   int st = check_spec(r->batch, r->max_points, r->dim, r->dtype);
   if (st != HK_OK) return st;
-  if (r->steps < 0) return HK_ERR_SHAPE;
+  if (r->steps < 0 || r->gen_max_value < 0 || r->episodes < 0) return HK_ERR_SHAPE;
   prm = Params{};
   prm.batch = r->batch;
   if (r->batch == 0) return HK_OK;
-  if (!r->points) return HK_ERR_NULL;
+  const bool gen = r->gen_max_value > 0;  // the initial states are drawn inside the launch
+  const int episodes = r->episodes > 1 ? r->episodes : 1;
+  const bool records = r->obs_out || r->host_class_out || r->axis_out || r->done_out || r->reward_out;
+  if (!gen && !r->points) return HK_ERR_NULL;
+  if (gen && (r->points_in || (r->gen_stages & ~(HK_STAGE_REPOSITION | HK_STAGE_NEWTON | HK_STAGE_RESCALE))))
+    return HK_ERR_UNSUPPORTED;
+  // (every episode starts from the initial state again: it has to be somewhere -- points_in, or the generator)
+  if (episodes > 1 && ((!gen && !r->points_in) || records)) return HK_ERR_UNSUPPORTED;
   if (r->dim < 2) return HK_ERR_SHAPE;  // the host needs a subset of >= 2 coordinates
-  if (!aligned(r->points, elem_size(r->dtype))) return HK_ERR_ALIGN;
+  if (r->points && !aligned(r->points, elem_size(r->dtype))) return HK_ERR_ALIGN;
   if (r->done_count && !aligned(r->done_count, 8)) return HK_ERR_ALIGN;
   if (r->host_policy < HK_HOST_RANDOM || r->host_policy > HK_HOST_ZEILLINGER) return HK_ERR_UNSUPPORTED;
   if (r->agent_policy < HK_AGENT_RANDOM || r->agent_policy > HK_AGENT_CHOOSE_LAST) return HK_ERR_UNSUPPORTED;
   if (r->stages & ~(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON | HK_STAGE_RESCALE)) return HK_ERR_UNSUPPORTED;
   if ((r->flags & HK_SEM_MASK) == HK_SEM_MASK) return HK_ERR_UNSUPPORTED;
   if (r->points_in && !aligned(r->points_in, elem_size(r->dtype))) return HK_ERR_ALIGN;
-  prm.in = r->points_in ? r->points_in : r->points;
+  prm.in = gen ? nullptr : (r->points_in ? r->points_in : r->points);
   prm.out = r->points;
   prm.in_stride = prm.out_stride = (int64_t)r->max_points * r->dim;
   prm.coords_kind = HK_COORDS_NONE;
@@ -417,13 +424,36 @@ static int params_from_rollout(const hk_rollout_desc* r, Params& prm) {
   prm.stages = r->stages;
   prm.flags = r->flags & ~HK_FLAG_DEFER_COUNTS;  // host-side only: the kernels always add to the workspace
   prm.mode = kModeRollout;
+  prm.max_value = gen ? r->gen_max_value : 0;
+  prm.gen_seed = r->gen_seed;
+  prm.gen_stages = r->gen_stages;
+  prm.episodes = episodes;
   return HK_OK;
+}
+
+// rollouts with generated initial states and / or several episodes as ONE launch (hk_quadroll_kernel.h: GEN)
+static bool use_quadroll_gen(const Params& prm, int dtype) {
+  if (prm.max_value <= 0) return false;
+  Params probe = prm;
+  probe.flags &= ~(unsigned)HK_FLAG_FORCE_FOUR_LANES;
+  return quadroll_gen_supported(probe, dtype);
+}
+
+// the geometry of the launch(es) that will serve a rollout request (a request the fused kernel declines is served by
+// hk_generate_points + a rollout per episode: the plain request's kernels)
+static Params rollout_geometry(Params prm, int dtype) {
+  if (!use_quadroll_gen(prm, dtype)) {
+    prm.max_value = 0;
+    prm.episodes = 1;
+    if (!prm.in) prm.in = prm.out;
+  }
+  return prm;
 }
 
 uint64_t hk_rollout_workspace_bytes(const hk_rollout_desc* r) {
   Params prm{};
   if (params_from_rollout(r, prm) != HK_OK || prm.batch == 0) return 0;
-  return (uint64_t)count_slots(prm, r->dtype) * (uint64_t)(r->steps + 1) * sizeof(uint32_t);
+  return (uint64_t)count_slots(rollout_geometry(prm, r->dtype), r->dtype) * (uint64_t)(r->steps + 1) * sizeof(uint32_t);
 }
 
 // workspace checks shared by hk_rollout and hk_rollout_reduce_counts
@@ -440,15 +470,43 @@ int hk_rollout(const hk_rollout_desc* r, void* stream) {
   const int st = params_from_rollout(r, prm);
   if (st != HK_OK) return st;
   if (prm.batch == 0) return HK_OK;
-  if (planned_grid(prm, r->dtype) == 0) return HK_ERR_UNSUPPORTED;
-  const int64_t slots = count_slots(prm, r->dtype);
+  const bool fused = use_quadroll_gen(prm, r->dtype);
+  const bool gen = prm.max_value > 0;
+  // what the fused kernel declines runs as hk_generate_points + a rollout per episode: the state then needs a buffer
+  // (and a generated batch re-ordered by ids exists inside the fused kernel only)
+  if (gen && !fused && (!r->points || r->game_ids)) return HK_ERR_UNSUPPORTED;
+  const Params geo = rollout_geometry(prm, r->dtype);
+  if (planned_grid(geo, r->dtype) == 0) return HK_ERR_UNSUPPORTED;
+  const int64_t slots = count_slots(geo, r->dtype);
   const bool defer = (r->flags & HK_FLAG_DEFER_COUNTS) != 0;
   if (r->done_count || defer) {
     const int ws = counts_workspace(r, slots, &prm.count_ws);
     if (ws != HK_OK) return ws;
   }
   prm.count_stride = (uint32_t)slots;
-  const int ls = launch(prm, r->dtype, (hipStream_t)stream);
+  int ls = HK_OK;
+  if (fused) {
+    prm.flags &= ~kHostSideFlags;  // (the compiled rollout configurations compare flags)
+    ls = launch_quadroll_gen(prm, (hipStream_t)stream);
+  } else {
+    const int episodes = prm.episodes;
+    for (int e = 0; e < episodes && ls == HK_OK; ++e) {
+      Params p = prm;
+      p.max_value = 0;
+      p.episodes = 1;
+      p.seed = prm.seed + (uint64_t)e;
+      if (gen) {
+        ls = hk_generate_points(r->points, r->batch, r->max_points, r->dim, r->dtype, r->gen_max_value,
+                                r->gen_seed + (uint64_t)e, r->game_offset, r->gen_stages, r->padding_value,
+                                r->flags & (HK_SEM_MASK | HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_TEAM | HK_FLAG_FORCE_ONE_LANE |
+                                            HK_FLAG_FORCE_TWO_LANES | HK_FLAG_FORCE_FOUR_LANES),
+                                stream);
+        if (ls != HK_OK) break;
+        p.in = r->points;
+      }
+      ls = launch(p, r->dtype, (hipStream_t)stream);
+    }
+  }
   if (ls != HK_OK || !r->done_count || defer) return ls;
   return launch_count_reduce(prm.count_ws, (int)slots, r->steps, (unsigned long long*)r->done_count,
                              (hipStream_t)stream);
@@ -457,14 +515,14 @@ int hk_rollout(const hk_rollout_desc* r, void* stream) {
 int hk_rollout_reduce_counts(const hk_rollout_desc* desc, void* stream) {
   if (!desc) return HK_ERR_NULL;
   hk_rollout_desc copy = *desc;  // only the launch geometry matters here: `points` may be NULL
-  if (!copy.points) copy.points = copy.workspace;
+  if (!copy.points && copy.gen_max_value <= 0) copy.points = copy.workspace;
   const hk_rollout_desc* r = &copy;
   Params prm{};
   const int st = params_from_rollout(r, prm);
   if (st != HK_OK) return st;
   if (!r->done_count) return HK_ERR_NULL;
   if (prm.batch == 0) return HK_OK;
-  const int64_t slots = count_slots(prm, r->dtype);
+  const int64_t slots = count_slots(rollout_geometry(prm, r->dtype), r->dtype);
   if (slots == 0) return HK_ERR_UNSUPPORTED;
   uint32_t* ws = nullptr;
   const int wst = counts_workspace(r, slots, &ws);

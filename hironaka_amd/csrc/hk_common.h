@@ -88,6 +88,11 @@ struct Params {
   int32_t feat_scale;  // rescale before the sort (scale_observation)
   // rollouts: the policy stream's game index of position g is game_offset + game_ids[g] (NULL: game_offset + g)
   const int32_t* game_ids;
+  // rollouts from initial states drawn inside the launch (hk_rollout_desc.gen_max_value > 0: `max_value` holds it, `in`
+  // is NULL and `out` may be) and episodes back to back
+  uint64_t gen_seed;
+  uint32_t gen_stages;
+  int32_t episodes;  // >= 1
 };
 
 // hipGetLastError() is sticky per host thread and other users of the runtime in this process

@@ -249,7 +249,8 @@ __device__ __forceinline__ void qg_newton_packed(float (&q)[R * D], uint32_t* sc
 }
 
 // the generator's stages on all R slots (every row live: ranks = row indices); returns the GAME's number of live rows
-template <int M, int D, int RD>
+// TWO: the float fallback of many slots per lane may use qd_newton_two_level (`tsc`: its 128 B of scratch per game)
+template <int M, int D, int RD, bool TWO = true>
 __device__ __forceinline__ int qg_stages(float (&q)[RD], int j, unsigned flags, unsigned stages, float* cmine,
                                          uint8_t* tsc, int max_value, int lane) {
   using G = QuadGeom<M, D>;
@@ -263,7 +264,7 @@ __device__ __forceinline__ int qg_stages(float (&q)[RD], int j, unsigned flags, 
   if (stages & HK_STAGE_REPOSITION) qd_reposition<R, D, R>(q, flags);
   if ((stages & HK_STAGE_NEWTON) && !packed) {
     if constexpr (R > kQuadDppSlots) {
-      if constexpr (QuadGenGeom<M, D>::kTwoLevel) qd_newton_two_level<M, G::CW, R, D, R>(q, cmine, tsc, j, M);
+      if constexpr (TWO && QuadGenGeom<M, D>::kTwoLevel) qd_newton_two_level<M, G::CW, R, D, R>(q, cmine, tsc, j, M);
       else qd_newton_lds<M, G::CW, R, D, R>(q, cmine, j, M);
     } else {
       qd_newton<R, D, R>(q, j);

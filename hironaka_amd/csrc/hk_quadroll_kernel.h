@@ -28,6 +28,7 @@
 #pragma once
 
 #include "hk_quad_kernel.h"
+#include "hk_quadgen_kernel.h"
 
 namespace hk {
 
@@ -313,10 +314,16 @@ __device__ __forceinline__ int qr_zeillinger(const float (&q)[R * D], float* cmi
 // registers and stored as one slab) and / or the small records (host class, axis, done, reward) -- what the
 // simulate-shaped consumers read (hironaka/jax/simulation_fn.py:196-211).  Once every game of the wave is at its
 // fixed point only the stores go on (the same image, the policies' draws, done = 1, reward = 0).
-template <int M, int D, int HOT, int WPB, bool REC = false, bool ZEIL = false>
+// GEN: the initial states are drawn inside the launch (hk_rollout_desc.gen_max_value: hk_quadgen_kernel.h's rows ->
+// the generator's stages on all slots -> one re-deal into the wave's bucket) and `episodes` of them run back to back --
+// episode e with seed + e and gen_seed + e, the counts accumulating; prm.out may be NULL (no final state is stored):
+// the whole loop of JAXTrainer.compute_rho (jax_trainer.py:502-555) without a byte of state traffic.
+template <int M, int D, int HOT, int WPB, bool REC = false, bool ZEIL = false, bool GEN = false>
 __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) void quadroll_kernel(
     const float* in0, int64_t in_stride0, int batch0, const Params prm) {
   static_assert(!ZEIL || (!REC && HOT == kHotNone), "Zeillinger's host: plain rollouts, policies inside the loop");
+  static_assert(!GEN || !REC, "generated initial states: plain rollouts");
+  static_assert(!GEN || QuadRollGeom<M, D>::kRegion >= QuadGenGeom<M, D>::kRegion, "the generator's staging image lies in the region");
   using G = QuadGeom<M, D>;
   using RG = QuadRollGeom<M, D>;
   constexpr int R = RG::R, CW = RG::CW;
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   uint32_t raw_id = 0;
   if (has_ids && fill_game < ngames) raw_id = (uint32_t)prm.game_ids[g0 + fill_game];
   __builtin_amdgcn_sched_barrier(0);
-  quad_slab_load<M, D>(in0 + g0 * G::N, region, ngames, lane);
+  if constexpr (!GEN) quad_slab_load<M, D>(in0 + g0 * G::N, region, ngames, lane);
   __builtin_amdgcn_sched_barrier(0);
   const float pad = prm.pad_f32;
   const unsigned flags = (HOT == kHotJax) ? (unsigned)HK_SEM_JAX : (HOT == kHotTorch) ? kHotTorchFlags : prm.flags;
@@ -353,19 +360,42 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   const float fill = ((flags & HK_SEM_MASK) == HK_SEM_JAX) ? -1.0f : pad;
   const int nsteps = prm.steps;
   uint32_t step0 = prm.step_offset;
-  uint64_t seed = prm.seed;
   int host_policy = prm.host_policy, agent_policy = prm.agent_policy;
-  asm volatile("" : "+s"(step0), "+s"(seed), "+s"(host_policy), "+s"(agent_policy));
-  // the first window of decoded actions, computed while the slab is in flight
+  asm volatile("" : "+s"(step0), "+s"(host_policy), "+s"(agent_policy));
   const uint64_t gg_fill = prm.game_offset + (has_ids ? (uint64_t)raw_id : (uint64_t)(g0 + fill_game));
+  const uint32_t wb_last = nsteps > 0 ? (step0 + (uint32_t)nsteps - 1u) >> 2 : step0 >> 2;
+  float* mine = region + gi * G::N;
+  const int episodes = GEN ? prm.episodes : 1;
+  for (int ep = 0;; ++ep) {  // (GEN: `episodes` of them; the loop's body is not indented)
+  const bool last_episode = !GEN || ep + 1 >= episodes;
+  uint64_t seed = prm.seed + (uint64_t)ep;
+  asm volatile("" : "+s"(seed));
+  // the first window of decoded actions, computed while the slab is in flight
   uint32_t wb0 = step0 >> 2;  // first Philox block of the window (wave-uniform)
-  const uint32_t wb_last = nsteps > 0 ? (step0 + (uint32_t)nsteps - 1u) >> 2 : wb0;
   if constexpr (!ZEIL) {
     const uint32_t nb = wb_last - wb0 + 1u;
     qr_policy_fill<D>(act, gg_fill, wb0, (int)(nb < (uint32_t)kQrBlocks ? nb : (uint32_t)kQrBlocks), seed, host_policy,
                       agent_policy, lane);
   }
-  float* mine = region + gi * G::N;
+  float q[R * D];
+  int orig[R];
+  int np, smax;
+  float* cmine = region + gi * (M * CW);
+  uint8_t* tmine = tags + gi * M;
+  if constexpr (GEN) {
+    // ---- a fresh game per quad: slot s of lane j = row 4 s + j, every row live; the generator's stages on all R slots;
+    // then the quads re-deal into the wave's bucket (rank = popcounts, as between two steps) -------------------------------
+    wave_lds_fence();
+    const uint64_t gg_gen = prm.game_offset + (has_ids ? (uint64_t)(uint32_t)__shfl((int)raw_id, gi) : (uint64_t)g);
+    qg_rows<M, D>(q, region, gg_gen, prm.gen_seed + (uint64_t)ep, (uint32_t)prm.max_value, j, gi);
+#pragma unroll
+    for (int s = 0; s < R; ++s) orig[s] = kQuad * s + j;
+    np = qg_stages<M, D, R * D, false>(q, j, flags, prm.gen_stages, cmine, nullptr, prm.max_value, lane);
+    smax = R;
+#pragma nounroll
+    while (smax > 1 && !__any(active && np > kQuad * (smax - 1))) --smax;
+    if (smax < R) qr_redeal<M, CW, R, D, R>(q, orig, cmine, tmine, j, active ? np : 0, smax);
+  } else {
   wait_vmem_all();
   wave_lds_fence();
 
@@ -415,7 +445,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
     gmask = ((unsigned long long)q_or((uint32_t)(mm >> 32)) << 32) | q_or((uint32_t)mm);
     below = __popcll(gmask & ((1ull << i0) - 1ull));
   }
-  int np = mask_pop(gmask);
+  np = mask_pop(gmask);
   const bool exact = (fill == pad) && !__any(bad != 0);
 
   if (!exact) {
@@ -473,8 +503,6 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
 
   // ---- compaction: every live row to the slot of its rank (the compact image lies over the slab image: every lane
   // holds its rows in registers by now), its index in the game next to it -------------------------------------------------
-  float* cmine = region + gi * (M * CW);
-  uint8_t* tmine = tags + gi * M;
   {
     int rank = below;
 #pragma unroll
@@ -495,14 +523,12 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
       rank += live ? 1 : 0;
     }
   }
-  int smax = R;
+  smax = R;
 #pragma nounroll
   while (smax > 1 && !__any(np > kQuad * (smax - 1))) --smax;
   wave_lds_fence();
 
   // ---- my slots: ranks j, j + 4, ... up to the wave's smax; slots past the game's live rows are holes -------------------
-  float q[R * D];
-  int orig[R];
 #pragma unroll
   for (int e = 0; e < R * D; ++e) q[e] = INFINITY;
 #pragma unroll
@@ -530,6 +556,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
     return true;
   });
   wave_lds_fence();
+  }  // (!GEN)
   if (!active) np = 2;  // never finished, never counted
   int length = (np < 2) ? 0 : -1;
 
@@ -652,10 +679,11 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
       }
     });
   }
-  if (leader && prm.game_length_out) prm.game_length_out[g] = length;
+  if (leader && last_episode && prm.game_length_out) prm.game_length_out[g] = length;
 
-  // ---- publish: padding everywhere, the survivors at their own rows ---------------------------------------------------
-  qr_build_image<M, D, R>(q, orig, region, mine, smax, pad, lane);
+  // ---- publish: padding everywhere, the survivors at their own rows (GEN: the last episode's, if anybody asks) -----------
+  const bool publish = !GEN || (last_episode && prm.out != nullptr);
+  if (publish) qr_build_image<M, D, R>(q, orig, region, mine, smax, pad, lane);
   if constexpr (REC) {
     // every game of the wave at its fixed point before the last step: the state does not change any more, the
     // observations go on (the same image); the records of a window are written before it moves
@@ -676,9 +704,12 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   }
   // (non-temporal: the final state is written once and not read again by the launch -- kept out of the XCD's L2 it
   // leaves the next episode's initial states there, hk_duo_kernel.h)
-  quad_slab_store<M, D, !REC>(region, (float*)prm.out + g0 * G::N, ngames, lane);
+  if (publish) quad_slab_store<M, D, !REC>(region, (float*)prm.out + g0 * G::N, ngames, lane);
   // the finished-game counts: games whose first finished step is <= s, for every s (a finished game stays finished)
   if (prm.count_ws) add_length_counts(prm.count_ws + blockIdx.x, prm.count_stride, 0, nsteps, leader, length, lane);
+  if (last_episode) break;
+  wave_lds_fence();  // (the next episode's action window and staging image)
+  }  // episodes
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
@@ -739,6 +770,51 @@ inline bool quadroll_supported(const Params& prm, int dtype) {
   return false;
 }
 
+// ---- rollouts from initial states drawn inside the launch (hk_rollout_desc.gen_max_value) ------------------------------
+// plain rollouts (no records), in-place order, a duplicate fill equal to the padding value (there is no exactness guard
+// to send anything else down the generic routines: the draws are canonical by construction); Zeillinger's host where
+// this kernel is its rollout kernel anyway (the large games)
+template <int M, int D>
+int launch_quadroll_gen_t(Params prm, hipStream_t stream) {
+  constexpr int WPB = QuadRollGeom<M, D>::kWpb;
+  const int64_t waves = ((int64_t)prm.batch + kQuadGames - 1) / kQuadGames;
+  const unsigned grid = (unsigned)((waves + WPB - 1) / WPB);
+  prm.games_per_block = kQuadGames * WPB;
+  prm.pad_f32 = (float)prm.pad;
+  launch_prepare();
+  const int hot = fast_hot_config(prm);
+  if (prm.host_policy == HK_HOST_ZEILLINGER) {
+    if constexpr (M > 32)
+      hipLaunchKernelGGL((quadroll_kernel<M, D, kHotNone, WPB, false, true, true>), dim3(grid), dim3(kWave * WPB), 0, stream,
+                         (const float*)nullptr, prm.in_stride, prm.batch, prm);
+    else
+      return HK_ERR_UNSUPPORTED;
+  } else if (hot == kHotJax) {
+    hipLaunchKernelGGL((quadroll_kernel<M, D, kHotJax, WPB, false, false, true>), dim3(grid), dim3(kWave * WPB), 0, stream,
+                       (const float*)nullptr, prm.in_stride, prm.batch, prm);
+  } else if (hot == kHotTorch) {
+    hipLaunchKernelGGL((quadroll_kernel<M, D, kHotTorch, WPB, false, false, true>), dim3(grid), dim3(kWave * WPB), 0, stream,
+                       (const float*)nullptr, prm.in_stride, prm.batch, prm);
+  } else {
+    hipLaunchKernelGGL((quadroll_kernel<M, D, kHotNone, WPB, false, false, true>), dim3(grid), dim3(kWave * WPB), 0, stream,
+                       (const float*)nullptr, prm.in_stride, prm.batch, prm);
+  }
+  return launch_status();
+}
+
+inline bool quadroll_gen_supported(const Params& prm, int dtype) {
+  if (dtype != HK_F32 || prm.max_value <= 0 || !quadroll_request_ok(prm)) return false;
+  if (prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out) return false;
+  if (prm.host_policy == HK_HOST_ZEILLINGER && prm.m <= 32) return false;
+  const float pad = (float)prm.pad;
+  if (!(pad < 0.0f) || ((prm.flags & HK_SEM_MASK) == HK_SEM_JAX && pad != -1.0f)) return false;
+#define HK_X(M_, D_) \
+  if (prm.m == M_ && prm.d == D_) return reinterpret_cast<uintptr_t>(prm.out) % (QuadGeom<M_, D_>::W * 4) == 0;
+  HK_QUAD_SPECS(HK_X)
+#undef HK_X
+  return false;
+}
+
 // where this kernel is the default: the shapes without a two-lane kernel ((50,4): hk::team_kernel's rollouts before)
 // ... and, on the small shapes, batches of up to two of its waves per SIMD (32 768 games on an MI355X): measured
 // (scripts/probe_rollout_families.py, (20,3)): 14.0 / 15.0 / 17.4 us per 20-step episode at 4 096 / 16 384 / 32 768 games against
@@ -774,9 +850,17 @@ inline int64_t quadroll_grid(const Params& prm) {
 }
 
 #ifndef HK_SPEC_TU
-#define HK_X(M_, D_) extern template int launch_quadroll_t<M_, D_>(Params, hipStream_t);
+#define HK_X(M_, D_) extern template int launch_quadroll_t<M_, D_>(Params, hipStream_t); \
+  extern template int launch_quadroll_gen_t<M_, D_>(Params, hipStream_t);
 HK_QUAD_SPECS(HK_X)
 #undef HK_X
+
+inline int launch_quadroll_gen(const Params& prm, hipStream_t stream) {
+#define HK_X(M_, D_) if (prm.m == M_ && prm.d == D_) return launch_quadroll_gen_t<M_, D_>(prm, stream);
+  HK_QUAD_SPECS(HK_X)
+#undef HK_X
+  return HK_ERR_UNSUPPORTED;
+}
 
 inline int launch_quadroll(const Params& prm, hipStream_t stream) {
 #define HK_X(M_, D_) if (prm.m == M_ && prm.d == D_) return launch_quadroll_t<M_, D_>(prm, stream);

@@ -496,6 +496,72 @@ def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0
     return res
 
 
+def rollout_generated(batch: int, spec: Tuple[int, int], steps: int, seed: int, *, max_value: int,
+                      gen_seed: Optional[int] = None, newton: bool = True, reposition: bool = True, rescale: bool = False,
+                      episodes: int = 1, game_offset: int = 0, step_offset: int = 0,
+                      host_policy: int = A.HK_HOST_RANDOM, agent_policy: int = A.HK_AGENT_RANDOM,
+                      stages: int = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON, flags: int = 0,
+                      padding_value: float = -1.0, dtype=torch.float32, device=None,
+                      out: Optional[torch.Tensor] = None, record: Sequence[str] = (),
+                      done_count: Optional[torch.Tensor] = None, defer_counts: bool = False,
+                      workspace: Optional[torch.Tensor] = None,
+                      game_ids: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """hk_rollout from initial states drawn INSIDE the launch (hk_rollout_desc.gen_max_value, ABI 4): what
+    `generate_points(batch, m, d, max_value, gen_seed, ...)` followed by `rollout(..., steps, seed)` computes, without
+    the state ever touching memory -- the loop body of JAXTrainer.compute_rho (jax_trainer.py:502-555), `episodes` of them
+    back to back (episode e: seed + e, gen_seed + e; the counts accumulate).  `out`: optional [B, m, d] tensor for the
+    final state of the last episode (None: "counts only").  record: "game_length" (the last episode's).
+    Requests the fused kernel does not serve (other shapes / dtypes / flags) run as generate + rollout per episode
+    inside the library and then need `out`; without it they raise HironakaHipError(HK_ERR_UNSUPPORTED)."""
+    m, d = spec
+    dev = out.device if out is not None else (torch.device("cuda") if device is None else torch.device(device))
+    if dev.type != "cuda":
+        raise TypeError("rollout_generated needs a HIP device")
+    if out is not None:
+        _require_device(out, "out")
+        if out.shape != (batch, m, d) or not out.is_contiguous():
+            raise ValueError("out must be a contiguous [B, m, d] tensor")
+        dtype = out.dtype
+    r = A.hk_rollout_desc()
+    res: Dict[str, torch.Tensor] = {}
+    if game_ids is not None:
+        _require_device(game_ids, "game_ids")
+        if game_ids.dtype != torch.int32 or game_ids.shape != (batch,) or not game_ids.is_contiguous():
+            raise ValueError("game_ids must be a contiguous int32 [B] tensor")
+        r.game_ids = game_ids.data_ptr()
+    if defer_counts:
+        if workspace is None:
+            raise ValueError("defer_counts=True needs the caller's own workspace (ops.rollout_workspace)")
+        flags |= A.HK_FLAG_DEFER_COUNTS
+    elif done_count is None:
+        done_count = torch.zeros(steps + 1, dtype=torch.int64, device=dev)
+    elif done_count.dtype != torch.int64 or done_count.numel() != steps + 1 or not done_count.is_cuda:
+        raise ValueError("done_count must be an int64 device tensor of steps+1 elements")
+    if done_count is not None:
+        res["done_count"] = done_count
+    for key in record:
+        if key != "game_length":
+            raise ValueError(f"rollout_generated records game_length only. Got {key}.")
+        res[key] = torch.empty(batch, dtype=torch.int32, device=dev)
+    r.points = out.data_ptr() if out is not None else None
+    r.done_count = done_count.data_ptr() if (done_count is not None and not defer_counts) else None
+    r.game_length_out = res["game_length"].data_ptr() if "game_length" in res else None
+    r.seed, r.game_offset, r.step_offset = seed, game_offset, step_offset
+    r.padding_value, r.reward_sign = float(padding_value), 1.0
+    r.batch, r.max_points, r.dim, r.dtype, r.steps = batch, m, d, _TORCH2HK[dtype], steps
+    r.host_policy, r.agent_policy, r.stages, r.flags = host_policy, agent_policy, stages, flags | _forced_flags
+    r.gen_max_value, r.gen_seed = int(max_value), int(seed if gen_seed is None else gen_seed)
+    r.gen_stages, r.episodes = make_stages(False, reposition, newton, rescale), int(episodes)
+    with torch.cuda.device(dev):
+        ws = workspace if defer_counts else _workspace(dev, lib().hk_rollout_workspace_bytes(C.byref(r)))
+        r.workspace, r.workspace_bytes = ws.data_ptr(), ws.numel()
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        check(lib().hk_rollout(C.byref(r), stream), "hk_rollout")
+    if out is not None:
+        res["points"] = out
+    return res
+
+
 def bin_by_live_rows(points: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """Games re-ordered by their number of live rows, widest first (stable), and the permutation as int32 `game_ids`
     (position -> original index) for `rollout(..., game_ids=)`: a wave of the rollout kernels then holds games of one

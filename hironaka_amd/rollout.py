@@ -72,31 +72,26 @@ def compute_rho(host: Union[str, Callable], agent: Union[str, Callable], *, spec
     world_batch = batch_size if world_batch is None else world_batch
     totals = None
     if fused:
-        # the per-loop histograms are summed on the device: partial counts accumulate in one workspace over
-        # all loops and are reduced once (the reference sums them on the host, jax_trainer.py:513,533-534)
-        # The loops are independent batches: they alternate between two streams, so that the next batch's waves fill
-        # the SIMDs the current launch's early finishers leave idle (a launch of 65 536 games ends with its slowest
-        # waves: 15.4 us per episode with two in flight against 23.3 us one at a time, bench.py:
-        # overlapped_episodes).  The partial counts of both streams meet in one workspace (atomic adds).
-        workspace = None
+        # The reference's loop draws a fresh batch per iteration (jax/util.py:385-392) and reads nothing back but the
+        # histogram (jax_trainer.py:513,533-534).  ONE launch does all `num_of_loops` of them: the initial states are
+        # drawn inside the kernel (hk_rollout_desc.gen_max_value), episode e with seeds key + e, no state is stored
+        # (points = NULL), the per-step finished-game counts of all episodes accumulate in the launch's workspace and
+        # are reduced once.  A wave starts its next episode as soon as its own games are finished, so nothing waits for
+        # a launch's slowest waves.  Requests the fused kernel does not serve (other shapes / dtypes, Zeillinger's
+        # host on the small shapes) run as generate + rollout per episode inside the library, on a state buffer.
+        from ._lib import HironakaHipError
         dev = torch.device("cuda" if device is None else device)
-        with torch.cuda.device(dev):
-            main = torch.cuda.current_stream()
-            lanes = [main, torch.cuda.Stream()] if num_of_loops > 1 else [main]
-            lanes[-1].wait_stream(main)
-            for loop in range(num_of_loops):
-                with torch.cuda.stream(lanes[loop % len(lanes)]):
-                    pts = generate_pts(key + loop, (batch_size, m, d), max_value, dtype, False, reposition,
-                                       game_offset=game_offset, device=device)
-                    if workspace is None:
-                        workspace = ops.rollout_workspace(batch_size, max_length - 1, spec, dtype, pts.device)
-                        totals = torch.zeros(max_length, dtype=torch.int64, device=pts.device)
-                        lanes[-1].wait_stream(main)  # (the workspace's zero fill is ordered before both streams' use)
-                    ops.rollout(pts, max_length - 1, key + loop, game_offset=game_offset, host_policy=_HOSTS[host],
-                                agent_policy=_AGENTS[agent], stages=stages, defer_counts=True, workspace=workspace)
-            main.wait_stream(lanes[-1])
-            if workspace is not None:
-                ops.reduce_counts(workspace, totals, batch_size, max_length - 1, spec, dtype)
+        common = dict(max_value=max_value, gen_seed=key, reposition=reposition, episodes=num_of_loops,
+                      game_offset=game_offset, host_policy=_HOSTS[host], agent_policy=_AGENTS[agent], stages=stages,
+                      dtype=dtype, device=dev)
+        try:
+            res = ops.rollout_generated(batch_size, spec, max_length - 1, key, **common)
+        except HironakaHipError as e:
+            if e.status != A.HK_ERR_UNSUPPORTED:
+                raise
+            buf = torch.empty((batch_size, m, d), dtype=dtype, device=dev)
+            res = ops.rollout_generated(batch_size, spec, max_length - 1, key, out=buf, **common)
+        totals = res["done_count"]
         details = details_from_done_counts(_world_counts(totals, batch_size, world_batch), world_batch * num_of_loops)
         return rho_from_details(details), details
     # arbitrary callables: the reference's step-by-step loop over take_actions (one fused launch per step)

@@ -244,3 +244,30 @@ def rollout(points: np.ndarray, steps: int, seed: int, *, game_offset=0, step_of
     if record:
         rec["done"] = rec["done"].astype(bool)
     return p, rec
+
+
+def rollout_generated(batch: int, spec, steps: int, seed: int, *, max_value: int, gen_seed=None,
+                      gen_stages=A.HK_STAGE_NEWTON | A.HK_STAGE_REPOSITION, episodes=1, game_offset=0, step_offset=0,
+                      host_policy=A.HK_HOST_RANDOM, agent_policy=A.HK_AGENT_RANDOM,
+                      stages=A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON, flags=0,
+                      padding_value=-1.0, dtype=np.float32, game_ids=None):
+    """hk_rollout_desc.gen_max_value / episodes (ABI 4): the initial states are drawn per game (the generator stream,
+    seed gen_seed + e) and rolled out (seed + e), e = 0 .. episodes - 1; returns (final state of the last episode,
+    dict(done_count summed over the episodes, game_length of the last episode))."""
+    m, d = spec
+    p = np.empty((batch, m, d), dtype=dtype)
+    r = A.hk_rollout_desc()
+    if game_ids is not None:
+        ids = np.ascontiguousarray(game_ids, dtype=np.int32)
+        r.game_ids = _ptr(ids)
+    counts = np.zeros(steps + 1, dtype=np.uint64)
+    rec = dict(done_count=counts, game_length=np.empty(batch, dtype=np.int32))
+    r.points, r.done_count, r.game_length_out = _ptr(p), _ptr(counts), _ptr(rec["game_length"])
+    r.seed, r.game_offset, r.step_offset = seed, game_offset, step_offset
+    r.padding_value, r.reward_sign = padding_value, 1.0
+    r.batch, r.max_points, r.dim, r.dtype, r.steps = batch, m, d, _hk_dtype(p), steps
+    r.host_policy, r.agent_policy, r.stages, r.flags = host_policy, agent_policy, stages, flags
+    r.gen_max_value, r.gen_seed, r.gen_stages, r.episodes = max_value, seed if gen_seed is None else gen_seed, gen_stages, episodes
+    _check(lib().hko_rollout(C.byref(r)))
+    return p, rec
+

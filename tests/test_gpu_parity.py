@@ -720,6 +720,100 @@ def test_config4_shards_equal_the_whole_batch():
     assert torch.equal(total, rec_full["done_count"])
 
 
+@pytest.mark.parametrize("spec", [(10, 3), (20, 3), (20, 4), (50, 4), (8, 4), (7, 3)])
+def test_generated_rollouts_match_oracle(spec):
+    """hk_rollout_desc.gen_max_value / episodes (ABI 4): the initial states drawn inside the launch, counts only or with
+    the final state, one episode or several (seed + e, gen_seed + e; the counts accumulate, the last episode's state and
+    lengths are kept) -- the fused kernel (hk::quadroll_kernel<..., GEN>) on the shapes that have one, the library's
+    generate + rollout composition elsewhere and under forced families; against the oracle's generated rollouts and
+    against generate_points + rollout on the device."""
+    m, d = spec
+    torch_flags = ops.make_flags("torch", noop_if_invalid=True, ignore_ended=True)
+    torch_flags_o = CO.flags_of(sem="torch", noop_if_invalid=True, ignore_ended=True)
+    stages = A.HK_STAGE_SHIFT | A.HK_STAGE_REPOSITION | A.HK_STAGE_NEWTON
+    fused = spec in ((10, 3), (20, 3), (20, 4), (50, 4))
+    cases = [dict(b=b, T=T, E=1, hp=A.HK_HOST_RANDOM, ap=A.HK_AGENT_RANDOM, fp=0, fo=0, st=stages, mv=20, rs=False)
+             for b, T in ((1, 5), (16, 0), (17, 1), (250, 20), (301, 27))]
+    cases += [dict(b=200, T=20, E=E, hp=A.HK_HOST_RANDOM, ap=A.HK_AGENT_RANDOM, fp=0, fo=0, st=stages, mv=20, rs=False)
+              for E in (2, 5)]
+    cases += [dict(b=150, T=12, E=2, hp=A.HK_HOST_RANDOM, ap=A.HK_AGENT_RANDOM_LEGAL, fp=torch_flags, fo=torch_flags_o,
+                   st=stages, mv=20, rs=False),
+              dict(b=150, T=12, E=1, hp=A.HK_HOST_ALL_COORD, ap=A.HK_AGENT_CHOOSE_LAST, fp=0, fo=0,
+                   st=stages | A.HK_STAGE_RESCALE, mv=9, rs=True),
+              dict(b=150, T=9, E=3, hp=A.HK_HOST_ZEILLINGER, ap=A.HK_AGENT_RANDOM_LEGAL, fp=0, fo=0, st=stages, mv=20,
+                   rs=False),
+              dict(b=150, T=9, E=1, hp=A.HK_HOST_RANDOM, ap=A.HK_AGENT_RANDOM, fp=0, fo=0, st=stages, mv=300, rs=False)]
+    for c in cases:
+        gst = A.HK_STAGE_NEWTON | A.HK_STAGE_REPOSITION | (A.HK_STAGE_RESCALE if c["rs"] else 0)
+        want_p, want = CO.rollout_generated(c["b"], spec, c["T"], 31, max_value=c["mv"], gen_seed=77, gen_stages=gst,
+                                            episodes=c["E"], game_offset=9, step_offset=2, host_policy=c["hp"],
+                                            agent_policy=c["ap"], stages=c["st"], flags=c["fo"])
+        for fam in (0, A.HK_FLAG_FORCE_FOUR_LANES, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_GENERIC):
+            out = torch.empty((c["b"], m, d), device="cuda")
+            got = ops.rollout_generated(c["b"], spec, c["T"], 31, max_value=c["mv"], gen_seed=77, rescale=c["rs"],
+                                        episodes=c["E"], game_offset=9, step_offset=2, host_policy=c["hp"],
+                                        agent_policy=c["ap"], stages=c["st"], flags=c["fp"] | fam, out=out,
+                                        record=("game_length",))
+            assert np.array_equal(host(out), want_p), (c, fam)
+            assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"]), (c, fam)
+            assert np.array_equal(host(got["game_length"]), want["game_length"]), (c, fam)
+        # counts only: no state buffer at all (the fused kernel; elsewhere the library says so)
+        zeil_small = c["hp"] == A.HK_HOST_ZEILLINGER and m <= 32
+        if fused and not zeil_small:
+            got = ops.rollout_generated(c["b"], spec, c["T"], 31, max_value=c["mv"], gen_seed=77, rescale=c["rs"],
+                                        episodes=c["E"], game_offset=9, step_offset=2, host_policy=c["hp"],
+                                        agent_policy=c["ap"], stages=c["st"], flags=c["fp"])
+            assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"]), c
+        else:
+            from hironaka_amd._lib import HironakaHipError
+            with pytest.raises(HironakaHipError):
+                ops.rollout_generated(c["b"], spec, c["T"], 31, max_value=c["mv"], gen_seed=77, rescale=c["rs"],
+                                      episodes=c["E"], host_policy=c["hp"], agent_policy=c["ap"], stages=c["st"],
+                                      flags=c["fp"])
+    # one episode == generate_points + rollout on the device; with game ids (fused kernel only)
+    P = ops.generate_points(300, m, d, 20, seed=5, game_offset=3)
+    rec = ops.rollout(P, 15, 8, game_offset=3, record=("game_length",))
+    out = torch.empty_like(P)
+    got = ops.rollout_generated(300, spec, 15, 8, max_value=20, gen_seed=5, game_offset=3, out=out, record=("game_length",))
+    assert torch.equal(out, P) and torch.equal(got["done_count"], rec["done_count"])
+    assert torch.equal(got["game_length"], rec["game_length"])
+    if fused:
+        ids = np.random.default_rng(1).permutation(300).astype(np.int32)
+        want_p, want = CO.rollout_generated(300, spec, 15, 8, max_value=20, gen_seed=5, game_offset=3, game_ids=ids)
+        got = ops.rollout_generated(300, spec, 15, 8, max_value=20, gen_seed=5, game_offset=3, out=out,
+                                    record=("game_length",), game_ids=dev(ids))
+        assert np.array_equal(host(out), want_p)
+        assert np.array_equal(host(got["game_length"]), want["game_length"])
+        assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"])
+
+
+def test_episodes_from_resident_states_match_oracle():
+    """hk_rollout_desc.episodes with the initial states in memory (`initial`): every episode restarts from them with
+    seed + e; the counts accumulate, `points` keeps the last episode's final state"""
+    p0 = CO.generate_points(500, 20, 3, 20, 4)
+    total = np.zeros(21, dtype=np.uint64)
+    for e in range(3):
+        want_p, want = CO.rollout(p0, 20, 60 + e, record=False)
+        total += want["done_count"]
+    for fam in (0, A.HK_FLAG_FORCE_FOUR_LANES, A.HK_FLAG_FORCE_ONE_LANE):
+        P0, P = dev(p0.copy()), torch.empty((500, 20, 3), device="cuda")
+        r = A.hk_rollout_desc()
+        dc = torch.zeros(21, dtype=torch.int64, device="cuda")
+        gl = torch.empty(500, dtype=torch.int32, device="cuda")
+        r.points, r.points_in, r.done_count, r.game_length_out = P.data_ptr(), P0.data_ptr(), dc.data_ptr(), gl.data_ptr()
+        r.seed, r.padding_value, r.reward_sign, r.episodes = 60, -1.0, 1.0, 3
+        r.batch, r.max_points, r.dim, r.dtype, r.steps = 500, 20, 3, A.HK_F32, 20
+        r.stages, r.flags = 7, fam
+        import ctypes as C
+        from hironaka_amd._lib import check, lib
+        ws = ops.rollout_workspace(500, 20, (20, 3))
+        r.workspace, r.workspace_bytes = ws.data_ptr(), ws.numel()
+        check(lib().hk_rollout(C.byref(r), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "hk_rollout")
+        assert np.array_equal(host(P), want_p), fam
+        assert np.array_equal(host(dc).astype(np.uint64), total), fam
+        assert np.array_equal(host(gl), want["game_length"]), fam
+
+
 # ------------------------------------------------------------------------------------------
 # BASELINE sizes: oracle on a slice + size-independent properties on the whole batch
 # ------------------------------------------------------------------------------------------

@@ -378,12 +378,12 @@ def test_compute_rho_fused_equals_stepwise():
 
 
 @pytest.mark.parametrize("loops", [1, 2, 3, 5])
-def test_compute_rho_two_streams_equal_the_oracle(loops):
-    """compute_rho alternates its independent loops between two streams (one workspace of partial counts, one
-    reduction at the end): for 1 / 2 / an odd number of loops the histogram equals the sum of the oracle's per-loop
-    histograms -- the ordering of the workspace's zero fill, of both streams' launches and of the final reduction"""
+def test_compute_rho_one_launch_equals_the_oracle(loops):
+    """compute_rho with named policies is ONE launch (hk_rollout_desc.gen_max_value + episodes: the batches are drawn
+    inside the kernel, no state is stored): the histogram equals the sum of the oracle's per-loop histograms of
+    generate_points(key + loop) -> rollout(key + loop), for 1 / 2 / an odd number of loops, twice (cached workspace)"""
     kw = dict(spec=(20, 3), batch_size=1536, max_value=20, max_length=10, num_of_loops=loops, key=21)
-    for _ in range(2):  # (twice: the second call reuses cached workspaces / streams)
+    for _ in range(2):
         rho, det = compute_rho("random", "random_legal", **kw)
         want = np.zeros(10, dtype=np.int64)
         for loop in range(loops):
@@ -392,6 +392,22 @@ def test_compute_rho_two_streams_equal_the_oracle(loops):
             want += rec["done_count"].astype(np.int64)
         assert det == details_from_done_counts(torch.as_tensor(want), 1536 * loops)
         assert rho == pytest.approx(rho_from_details(det))
+
+
+@pytest.mark.parametrize("spec,host_name,dtype", [((50, 4), "zeillinger", torch.float32), ((20, 3), "zeillinger", torch.float32),
+                                                   ((7, 3), "random", torch.float32), ((10, 3), "random", torch.float64),
+                                                   ((20, 4), "all_coord", torch.float32)])
+def test_compute_rho_every_route_equals_the_oracle(spec, host_name, dtype):
+    """compute_rho by name on the fused kernel ((50,4) incl. Zeillinger's host, (20,4)) and on the library's generate +
+    rollout composition (Zeillinger's host on a small shape, a shape without a four-lane kernel, float64): the same
+    histogram as the oracle's generated rollouts"""
+    m, d = spec
+    hp = {"random": A.HK_HOST_RANDOM, "zeillinger": A.HK_HOST_ZEILLINGER, "all_coord": A.HK_HOST_ALL_COORD}[host_name]
+    rho, det = compute_rho(host_name, "random", spec=spec, batch_size=700, max_value=20, max_length=9, num_of_loops=3,
+                           key=5, dtype=dtype)
+    _, want = CO.rollout_generated(700, spec, 8, 5, max_value=20, episodes=3, host_policy=hp,
+                                   dtype=np.float32 if dtype == torch.float32 else np.float64)
+    assert det == details_from_done_counts(torch.as_tensor(want["done_count"].astype(np.int64)), 2100)
 
 
 def test_simulate_shapes_and_values():
