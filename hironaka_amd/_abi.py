@@ -149,6 +149,10 @@ PROTOTYPES = {
     "hk_get_dones": (C.c_int, [_vp, _i64, _vp, _i, _i, _i, _i, _vp]),
     "hk_get_num_points": (C.c_int, [_vp, _i64, _vp, _i, _i, _i, _i, _vp]),
     "hk_generate_points": (C.c_int, [_vp, _i, _i, _i, _i, _i, _u64, _u64, _u32, _d, _u32, _vp]),
+    "hk_bin_group_games": (C.c_int, [_i, _i, _i]),
+    "hk_bin_unit_games": (C.c_int, [_i, _i, _i]),
+    "hk_generate_points_binned": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _u64, _u64, _u32, _d, _u32, _vp]),
+    "hk_bin_by_live_rows": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "hk_rollout": (C.c_int, [C.POINTER(hk_rollout_desc), _vp]),
     "hk_rollout_workspace_bytes": (C.c_uint64, [C.POINTER(hk_rollout_desc)]),
     "hk_rollout_reduce_counts": (C.c_int, [C.POINTER(hk_rollout_desc), C.c_void_p]),

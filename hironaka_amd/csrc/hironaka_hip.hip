@@ -6,6 +6,7 @@
 #include "hk_quad_kernel.h"
 #include "hk_quadroll_kernel.h"
 #include "hk_quadgen_kernel.h"
+#include "hk_quadbin_kernel.h"
 #include "hk_team_kernel.h"
 #include "hk_search.h"
 #include "hk_generic_kernel.h"
@@ -373,6 +374,64 @@ int hk_generate_points(void* points_out, int batch, int max_points, int dim, int
   prm.flags = flags;
   prm.mode = kModeGenerate;
   return launch(prm, dtype, (hipStream_t)stream);
+}
+
+// ---- games binned by live rows (hk_quadbin_kernel.h) -------------------------------------------------------------------
+int hk_bin_group_games(int max_points, int dim, int dtype) { return quadbin_group_games(max_points, dim, dtype); }
+int hk_bin_unit_games(int max_points, int dim, int dtype) {
+  return quadbin_group_games(max_points, dim, dtype) ? kQuadGames : 0;
+}
+
+static int bin_common(const void* in, void* points_out, int32_t* ids, int32_t* np_out, int batch, int m, int d, int dtype) {
+  int st = check_spec(batch, m, d, dtype);
+  if (st != HK_OK) return st;
+  if (batch == 0) return HK_OK;
+  if (!points_out || !ids) return HK_ERR_NULL;
+  if (!quadbin_group_games(m, d, dtype)) return HK_ERR_UNSUPPORTED;
+  if (!aligned(points_out, 16) || (in && !aligned(in, 16))) return HK_ERR_ALIGN;
+  if (!aligned(ids, 4) || (np_out && !aligned(np_out, 4))) return HK_ERR_ALIGN;
+  return HK_OK;
+}
+
+int hk_generate_points_binned(void* points_out, int32_t* game_ids_out, int32_t* num_points_out, int batch, int max_points,
+                              int dim, int dtype, int max_value, uint64_t seed, uint64_t game_offset, uint32_t stages,
+                              double padding_value, uint32_t flags, void* stream) {
+  const int st = bin_common(nullptr, points_out, game_ids_out, num_points_out, batch, max_points, dim, dtype);
+  if (st != HK_OK || batch == 0) return st;
+  if (max_value < 1) return HK_ERR_SHAPE;
+  if (stages & ~(HK_STAGE_REPOSITION | HK_STAGE_NEWTON | HK_STAGE_RESCALE)) return HK_ERR_UNSUPPORTED;
+  Params prm{};
+  prm.out = points_out;
+  prm.out_stride = prm.in_stride = (int64_t)max_points * dim;
+  prm.coords_kind = HK_COORDS_NONE;
+  prm.seed = seed;
+  prm.game_offset = game_offset;
+  prm.max_value = max_value;
+  prm.pad = padding_value;
+  prm.batch = batch;
+  prm.m = max_points;
+  prm.d = dim;
+  prm.stages = stages;
+  prm.flags = flags & ~(unsigned)HK_FLAG_FORCE_FOUR_LANES;
+  prm.mode = kModeGenerate;
+  if (!quadgen_supported(prm, dtype)) return HK_ERR_UNSUPPORTED;  // (what the four-lane generator serves)
+  return launch_quadbin(prm, nullptr, game_ids_out, num_points_out, (hipStream_t)stream);
+}
+
+int hk_bin_by_live_rows(const void* points_in, void* points_out, int32_t* game_ids_out, int32_t* num_points_out, int batch,
+                        int max_points, int dim, int dtype, void* stream) {
+  if (batch > 0 && !points_in) return HK_ERR_NULL;
+  const int st = bin_common(points_in, points_out, game_ids_out, num_points_out, batch, max_points, dim, dtype);
+  if (st != HK_OK || batch == 0) return st;
+  Params prm{};
+  prm.in = points_in;
+  prm.out = points_out;
+  prm.out_stride = prm.in_stride = (int64_t)max_points * dim;
+  prm.batch = batch;
+  prm.m = max_points;
+  prm.d = dim;
+  prm.pad = -1.0;
+  return launch_quadbin(prm, (const float*)points_in, game_ids_out, num_points_out, (hipStream_t)stream);
 }
 
 static int params_from_rollout(const hk_rollout_desc* r, Params& prm) {

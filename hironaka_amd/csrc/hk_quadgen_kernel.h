@@ -284,7 +284,6 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void 
   using GG = QuadGenGeom<M, D>;
   constexpr int R = G::R;
   __shared__ __align__(16) float lds_all[WPB * GG::kRegion];
-  __shared__ __align__(16) uint8_t tsc_all[GG::kTwoLevel ? WPB * kQuadGames * 128 : 16];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & (kWave - 1);
   float* region = lds_all + wave * GG::kRegion;
   const int j = lane & 3, gi = lane >> 2;
@@ -296,9 +295,12 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void 
   float q[R * D];
   qg_rows<M, D>(q, region, gg, prm.seed, (uint32_t)prm.max_value, j, gi);
   float* mine = region + gi * G::N;
-  uint8_t* tsc = GG::kTwoLevel ? tsc_all + (wave * kQuadGames + gi) * 128 : nullptr;
-  // (the parked rows of the big games' pair loops: the game's part of the region -- G::kGameStride == N there)
-  (void)qg_stages<M, D>(q, j, prm.flags, prm.stages, region + gi * G::kGameStride, tsc, prm.max_value, lane);
+  // (the parked rows of the big games' pair loops: the game's part of the region -- G::kGameStride == N there.  The
+  // float fallback of many slots per lane -- draws of 127 and more -- is the one-level loop: with qd_newton_two_level
+  // compiled in, the kernel needed 188 registers, two waves per SIMD, where the packed path gets by with 134 and three:
+  // 106 -> 93 us at (50,4) x 262 144)
+  (void)qg_stages<M, D, R * D, false>(q, j, prm.flags, prm.stages, region + gi * G::kGameStride, nullptr, prm.max_value,
+                                      lane);
   const float pad = prm.pad_f32;
 #pragma unroll
   for (int s = 0; s < R; ++s) {

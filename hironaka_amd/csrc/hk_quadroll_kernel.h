@@ -148,10 +148,14 @@ __device__ __forceinline__ void qr_policy_fill(uint8_t* act, uint64_t gg, uint32
 }
 
 // the quad's rows to their ranks in the compact image (rank order = (slot, lane) order = the order they had), the rows'
-// indices next to them; then slots [0, snew) back: lane j takes ranks j, j + 4, ...
+// indices next to them; then slots [0, snew) back: lane j takes ranks j, j + 4, ...  The index of the row in slot s of
+// lane j lives in tmine[4 s + j] between two deals, NOT in a register: it is looked at by the next deal and by the final
+// image only, and thirteen more loop-carried registers were part of what the (50,4) kernels spilled.
 template <int M, int CW, int R, int D, int NB>
-__device__ __forceinline__ void qr_redeal(float (&q)[R * D], int (&orig)[R], float* cmine, uint8_t* tmine, int j, int np,
-                                          int snew) {
+__device__ __forceinline__ void qr_redeal(float (&q)[R * D], float* cmine, uint8_t* tmine, int j, int np, int snew) {
+  // (opaque: the masks below depend on the lane only, and hoisted out of the step loops -- 3 per slot, live through the
+  // whole staircase -- they were most of the (50,4) kernels' 212 - 332 B of scratch per lane)
+  asm volatile("" : "+v"(j));
   uint32_t lm = 0;
 #pragma unroll
   for (int s = 0; s < NB; ++s) lm |= (q[s * D] < INFINITY) ? (1u << s) : 0u;
@@ -159,6 +163,12 @@ __device__ __forceinline__ void qr_redeal(float (&q)[R * D], int (&orig)[R], flo
                  l3 = (uint32_t)qperm_i<kQuadUp3>((int)lm);
   // the lane k up is lane (j + k) & 3 of the quad: its slot s comes before mine iff that lane index is below j
   const bool b1 = ((j + 1) & 3) < j, b2 = ((j + 2) & 3) < j, b3 = ((j + 3) & 3) < j;
+  uint32_t tg[NB];  // my rows' indices, read before any lane writes a new one
+#pragma unroll
+  for (int s = 0; s < NB; ++s) tg[s] = tmine[kQuad * s + j < M ? kQuad * s + j : 0];
+#pragma unroll
+  for (int s = 0; s < NB; ++s) asm volatile("" : "+v"(tg[s]));
+  wave_lds_fence();
 #pragma unroll
   for (int s = 0; s < NB; ++s) {
     const uint32_t below = (1u << s) - 1u, at = 1u << s;
@@ -174,7 +184,7 @@ __device__ __forceinline__ void qr_redeal(float (&q)[R * D], int (&orig)[R], flo
 #pragma unroll
         for (int k = 0; k < D; ++k) dst[k] = q[s * D + k];
       }
-      tmine[rank] = (uint8_t)orig[s];
+      tmine[rank] = (uint8_t)tg[s];
     }
   }
   wave_lds_fence();
@@ -201,17 +211,22 @@ __device__ __forceinline__ void qr_redeal(float (&q)[R * D], int (&orig)[R], flo
         q[s * D + k] = has ? v : INFINITY;
       }
     }
-    orig[s] = (int)tmine[r];
     return true;
   });
   wave_lds_fence();  // (the compact image is scratch again: qd_newton_lds parks rows there)
 }
 
 // the wave's image from the rows in registers: padding everywhere (16-B pieces), then every live row at its own place
-template <int M, int D, int R>
-__device__ __forceinline__ void qr_build_image(const float (&q)[R * D], const int (&orig)[R], float* region, float* mine,
-                                               int smax, float pad, int lane) {
+// (SB: compile-time bound of the slots in use -- the level of the staircase the caller is on)
+template <int M, int D, int R, int SB = R>
+__device__ __forceinline__ void qr_build_image(const float (&q)[R * D], const uint8_t* tags, float* region, int smax,
+                                               float pad, int j, int lane) {
   using G = QuadGeom<M, D>;
+  // (the game's addresses from the lane, here: as loop invariants they lived in registers through the whole staircase)
+  int gi = lane >> 2;
+  asm volatile("" : "+v"(gi));
+  const uint8_t* tmine = tags + gi * M;
+  float* mine = region + gi * G::N;
   wave_lds_fence();
 #pragma unroll
   for (int it = 0; it < G::QL; ++it) {
@@ -223,11 +238,11 @@ __device__ __forceinline__ void qr_build_image(const float (&q)[R * D], const in
     }
   }
   wave_lds_fence();
-  unrolled_while<0, R>([&](auto sc) {
+  unrolled_while<0, SB>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
     if (s >= smax) return false;
     if (q[s * D] < INFINITY) {
-      float* dst = mine + orig[s] * D;
+      float* dst = mine + (int)tmine[kQuad * s + j < M ? kQuad * s + j : 0] * D;  // (the row's index in the game)
       if constexpr (D == 4) {
         *reinterpret_cast<vf4*>(dst) = vf4{q[s * D], q[s * D + 1], q[s * D + 2], q[s * D + 3]};
       } else {
@@ -378,7 +393,6 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
                       agent_policy, lane);
   }
   float q[R * D];
-  int orig[R];
   int np, smax;
   float* cmine = region + gi * (M * CW);
   uint8_t* tmine = tags + gi * M;
@@ -389,12 +403,13 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
     const uint64_t gg_gen = prm.game_offset + (has_ids ? (uint64_t)(uint32_t)__shfl((int)raw_id, gi) : (uint64_t)g);
     qg_rows<M, D>(q, region, gg_gen, prm.gen_seed + (uint64_t)ep, (uint32_t)prm.max_value, j, gi);
 #pragma unroll
-    for (int s = 0; s < R; ++s) orig[s] = kQuad * s + j;
+    for (int s = 0; s < R; ++s)
+      if ((kQuad * s + kQuad <= M) || kQuad * s + j < M) tmine[kQuad * s + j] = (uint8_t)(kQuad * s + j);
     np = qg_stages<M, D, R * D, false>(q, j, flags, prm.gen_stages, cmine, nullptr, prm.max_value, lane);
     smax = R;
 #pragma nounroll
     while (smax > 1 && !__any(active && np > kQuad * (smax - 1))) --smax;
-    if (smax < R) qr_redeal<M, CW, R, D, R>(q, orig, cmine, tmine, j, active ? np : 0, smax);
+    if (smax < R) qr_redeal<M, CW, R, D, R>(q, cmine, tmine, j, active ? np : 0, smax);
   } else {
   wait_vmem_all();
   wave_lds_fence();
@@ -531,8 +546,6 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   // ---- my slots: ranks j, j + 4, ... up to the wave's smax; slots past the game's live rows are holes -------------------
 #pragma unroll
   for (int e = 0; e < R * D; ++e) q[e] = INFINITY;
-#pragma unroll
-  for (int s = 0; s < R; ++s) orig[s] = 0;
   unrolled_while<0, R>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
     if (s >= smax) return false;
@@ -552,7 +565,6 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
         q[s * D + k] = has ? v : INFINITY;
       }
     }
-    orig[s] = (int)tmine[r];
     return true;
   });
   wave_lds_fence();
@@ -601,17 +613,32 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   };
   int t = 0;
   bool stop = false;
+  // (GEN: the last episode's final state, if anybody asks)
+  const bool publish = !GEN || (last_episode && prm.out != nullptr);
+  bool published = !publish;
   PolicyCache zcache;  // (ZEIL: the lane's own Philox block, one per four steps)
   const uint64_t gg_game =  // (ZEIL) the policy stream's index of the game this lane plays
       ZEIL ? prm.game_offset + (has_ids ? (uint64_t)(uint32_t)__shfl((int)raw_id, gi) : (uint64_t)g) : 0;
+  if (nsteps <= 0 && !published) {  // (no step: no level of the staircase is entered)
+    qr_build_image<M, D, R, R>(q, tags, region, smax, pad, j, lane);
+    published = true;
+  }
   while (t < nsteps && !stop) {  // one pass per window of actions (episodes of up to 24 steps: one pass)
     if (!ZEIL && (uint32_t)((step0 + (uint32_t)t) >> 2) - wb0 >= (uint32_t)kQrBlocks) {
       if constexpr (REC) flush_records(t, length);
       wave_lds_fence();
       wb0 = (step0 + (uint32_t)t) >> 2;
+      asm volatile("" : "+s"(wb0));  // (the refill's Philox rounds stay in here: their invariant parts were hoisted and spilled)
       const uint32_t nb = wb_last - wb0 + 1u;
-      qr_policy_fill<D>(act, gg_fill, wb0, (int)(nb < (uint32_t)kQrBlocks ? nb : (uint32_t)kQrBlocks), seed, host_policy,
-                        agent_policy, lane);
+      // (the fill game's stream index again, from the lane: kept in registers from the first fill it was spilled)
+      int lane_r = lane;
+      asm volatile("" : "+v"(lane_r));
+      const int fill_r = lane_r & (kQuadGames - 1);
+      uint32_t id_r = 0;  // (the id is loaded again too: refills are rare, a register through all the loops is not)
+      if (has_ids && fill_r < ngames) id_r = (uint32_t)prm.game_ids[g0 + fill_r];
+      const uint64_t gg_refill = prm.game_offset + (has_ids ? (uint64_t)id_r : (uint64_t)(g0 + fill_r));
+      qr_policy_fill<D>(act, gg_refill, wb0, (int)(nb < (uint32_t)kQrBlocks ? nb : (uint32_t)kQrBlocks), seed, host_policy,
+                        agent_policy, lane_r);
       wave_lds_fence();
     }
     const uint32_t wstep0 = wb0 << 2;                       // first step of the window
@@ -639,7 +666,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
         }
         if constexpr (REC) {
           if (want_obs) {  // the state before the step
-            qr_build_image<M, D, R>(q, orig, region, mine, smax, pad, lane);
+            qr_build_image<M, D, R, NB>(q, tags, region, smax, pad, j, lane);
 #if !defined(HK_QR_EXP) || HK_QR_EXP != 2
             // (ordinary stores: 315 MB of non-temporal stores in this pattern take 61.6 us where ordinary ones take
             // 55.5 and a plain fill 47 -- scripts/probe_obs_pattern.py; the L2 write-back combines, the stream does not)
@@ -671,19 +698,23 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
             int snew = smax - 1;
 #pragma nounroll
             while (snew > 1 && !__any(active && np > kQuad * (snew - 1))) --snew;
-            qr_redeal<M, CW, R, D, NB>(q, orig, cmine, tmine, j, active ? np : 0, snew);
+            qr_redeal<M, CW, R, D, NB>(q, cmine, tmine, j, active ? np : 0, snew);
             smax = snew;
           }
         }
         ++t;
       }
+      // ---- publish, on the level the episode ends on: padding everywhere, the survivors at their own rows.  (After the
+      // staircase it would read every slot of every level: the whole row array stayed live through all the loops --
+      // at (50,4), 52 + 13 registers under a 168-register budget: every lane spilled 212 - 332 B.) -------------------------
+      if (!published && (t >= nsteps || stop)) {
+        qr_build_image<M, D, R, NB>(q, tags, region, smax, pad, j, lane);
+        published = true;
+      }
     });
   }
-  if (leader && last_episode && prm.game_length_out) prm.game_length_out[g] = length;
-
-  // ---- publish: padding everywhere, the survivors at their own rows (GEN: the last episode's, if anybody asks) -----------
-  const bool publish = !GEN || (last_episode && prm.out != nullptr);
-  if (publish) qr_build_image<M, D, R>(q, orig, region, mine, smax, pad, lane);
+  // (scalar base + the lane's game index: the 64-bit index g need not live through the loops)
+  if (leader && last_episode && prm.game_length_out) (prm.game_length_out + g0)[(unsigned)gi] = length;
   if constexpr (REC) {
     // every game of the wave at its fixed point before the last step: the state does not change any more, the
     // observations go on (the same image); the records of a window are written before it moves

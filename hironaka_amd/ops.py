@@ -562,18 +562,68 @@ def rollout_generated(batch: int, spec: Tuple[int, int], steps: int, seed: int, 
     return res
 
 
-def bin_by_live_rows(points: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Games re-ordered by their number of live rows, widest first (stable), and the permutation as int32 `game_ids`
-    (position -> original index) for `rollout(..., game_ids=)`: a wave of the rollout kernels then holds games of one
-    size -- its slots per lane are the widest game's -- and every game keeps its policy stream, so the re-ordered batch
-    rolls out exactly as the original one, game by game.  Done once, where the batch is generated (the reference's
-    batches carry no order: jax/util.py:385-392 draws them at random); the sort itself is tensor-library plumbing
-    around hk_get_num_points."""
+def bin_group(max_points: int, dim: int, dtype=torch.float32) -> Tuple[int, int]:
+    """(games per group, games per unit) of the on-device binning for a shape; (0, 0): no binning kernel."""
+    code = _TORCH2HK.get(dtype, -1)
+    return int(lib().hk_bin_group_games(max_points, dim, code)), int(lib().hk_bin_unit_games(max_points, dim, code))
+
+
+def bin_by_live_rows(points: torch.Tensor, out: Optional[torch.Tensor] = None,
+                     want_num_points: bool = False):
+    """Games re-ordered by their number of live rows and the permutation as int32 `game_ids` (position -> original
+    index) for `rollout(..., game_ids=)`: a wave of the rollout kernels then holds games of one size -- its slots per lane
+    are the widest game's -- and every game keeps its policy stream, so the re-ordered batch rolls out exactly as the
+    original one, game by game (the reference's batches carry no order: jax/util.py:385-392 draws them at random).
+    ONE launch (hk_bin_by_live_rows, ABI 4) on the shapes with a four-lane kernel: the order is local to groups of
+    `bin_group(...)[0]` consecutive games -- widest first, equal games in their order --, and the k-th sixteen games of
+    all groups lie together in the output, the widest stratum first (include/hironaka_hip.h).  Other shapes / dtypes: a
+    global stable sort with the tensor library.
+    Returns (binned points, game_ids) or, with want_num_points, (binned points, game_ids, live rows per position)."""
     _require_device(points, "points")
     if points.dim() != 3:
         raise ValueError("points must be [B, m, d]")
-    order = torch.argsort(get_num_points(points), descending=True, stable=True)
-    return points.index_select(0, order).contiguous(), order.to(torch.int32)
+    b, m, d = points.shape
+    if points.is_contiguous() and bin_group(m, d, points.dtype)[0]:
+        out = torch.empty_like(points) if out is None else out
+        if out.data_ptr() == points.data_ptr():
+            raise ValueError("bin_by_live_rows cannot work in place: a group's games leave for every stratum")
+        ids = torch.empty(b, dtype=torch.int32, device=points.device)
+        npts = torch.empty(b, dtype=torch.int32, device=points.device) if want_num_points else None
+        with torch.cuda.device(points.device):
+            check(lib().hk_bin_by_live_rows(points.data_ptr(), out.data_ptr(), ids.data_ptr(),
+                                            npts.data_ptr() if npts is not None else None, b, m, d,
+                                            _TORCH2HK[points.dtype], _stream(points)), "hk_bin_by_live_rows")
+        return (out, ids, npts) if want_num_points else (out, ids)
+    counts = get_num_points(points)
+    order = torch.argsort(counts, descending=True, stable=True)
+    binned = points.index_select(0, order).contiguous()
+    if out is not None:
+        out.copy_(binned)
+        binned = out
+    ids = order.to(torch.int32)
+    return (binned, ids, counts.index_select(0, order)) if want_num_points else (binned, ids)
+
+
+def generate_points_binned(batch: int, max_points: int, dim: int, max_value: int, seed: int, *, game_offset: int = 0,
+                           device=None, newton=True, reposition=True, rescale=False, padding_value: float = -1.0,
+                           flags: int = 0, out: Optional[torch.Tensor] = None, want_num_points: bool = False):
+    """generate_points + bin_by_live_rows as ONE launch (hk_generate_points_binned): the generator has every game's
+    rows in registers when it knows their count.  float32, the shapes with a four-lane kernel (HironakaHipError
+    otherwise: generate_points + bin_by_live_rows).  Returns (points, game_ids[, live rows per position])."""
+    dev = out.device if out is not None else (torch.device("cuda") if device is None else torch.device(device))
+    if out is None:
+        out = torch.empty((batch, max_points, dim), dtype=torch.float32, device=dev)
+    else:
+        _require_device(out, "out")
+    ids = torch.empty(batch, dtype=torch.int32, device=dev)
+    npts = torch.empty(batch, dtype=torch.int32, device=dev) if want_num_points else None
+    stages = make_stages(False, reposition, newton, rescale)
+    with torch.cuda.device(dev):
+        check(lib().hk_generate_points_binned(out.data_ptr(), ids.data_ptr(), npts.data_ptr() if npts is not None else None,
+                                              batch, max_points, dim, _TORCH2HK[out.dtype], max_value, seed, game_offset,
+                                              stages, float(padding_value), flags | _forced_flags, _stream(out)),
+              "hk_generate_points_binned")
+    return (out, ids, npts) if want_num_points else (out, ids)
 
 
 def has_fast_path(max_points: int, dim: int, dtype=torch.float32) -> bool:

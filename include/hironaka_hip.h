@@ -30,6 +30,7 @@
  *   hk_get_dones             jax/util.py:34-35, core/tensor_points.py:118-120
  *   hk_get_num_points        core/tensor_points.py:65-70
  *   hk_generate_points       jax/util.py:385-392 generate_pts, trainer/trainer.py:592-600
+ *   hk_generate_points_binned / hk_bin_by_live_rows   (no counterpart: an MI355X-side ordering of a batch)
  *   hk_rollout               jax/jax_trainer.py:502-555 compute_rho inner loop with
  *                            jax/players.py:28-39,142-212 fixed policies fused in
  *   hk_zeillinger            jax/players.py:55-109 zeillinger_fn, host.py:54-95 Zeillinger
@@ -254,6 +255,28 @@ int hk_get_num_points(const void* points, int64_t stride, int32_t* num_points_ou
 int hk_generate_points(void* points_out, int batch, int max_points, int dim, int dtype,
                        int max_value, uint64_t seed, uint64_t game_offset, uint32_t stages,
                        double padding_value, uint32_t flags, void* stream);
+
+/* ---- games binned by live rows (ABI 4; no reference counterpart: its batches carry no order, jax/util.py:385-392) ----
+ * A wave of the rollout kernels runs the body of its widest game, so neighbours of one size roll out faster; with the
+ * permutation as hk_rollout_desc.game_ids every game keeps its policy stream: the re-ordered batch plays, game by game,
+ * what the original order plays.  The order is local to groups of G = hk_bin_group_games(...) consecutive games (one
+ * workgroup each): inside a group the games are ranked by live rows (x_0 >= 0, hk_get_num_points), widest first, equal
+ * ones in their original order.  With U = hk_bin_unit_games(...) (16) and F = batch / G full groups, the game of rank p in
+ * full group k goes to position (p / U) * F * U + k * U + p % U: the k-th units of all the groups lie together, the
+ * widest stratum first -- the rollout kernels' workgroups start with the heavy waves and every XCD gets every weight.
+ * A partial last group is ranked in place, behind the strata.
+ * points_out [batch, max_points*dim], game_ids_out [batch] (position -> index in the batch), num_points_out [batch] or NULL
+ * (live rows of the game at each position).  float32 and the shapes with a four-lane kernel; else HK_ERR_UNSUPPORTED.
+ * hk_generate_points_binned = hk_generate_points with that order applied before the states are stored (one launch: the
+ * generator has every game's rows in registers); hk_bin_by_live_rows re-orders an existing batch (NOT in place: a
+ * workgroup's games leave for every stratum).                                                                        */
+int hk_bin_group_games(int max_points, int dim, int dtype); /* 0: no binning kernel for the shape */
+int hk_bin_unit_games(int max_points, int dim, int dtype);
+int hk_generate_points_binned(void* points_out, int32_t* game_ids_out, int32_t* num_points_out, int batch, int max_points,
+                              int dim, int dtype, int max_value, uint64_t seed, uint64_t game_offset, uint32_t stages,
+                              double padding_value, uint32_t flags, void* stream);
+int hk_bin_by_live_rows(const void* points_in, void* points_out, int32_t* game_ids_out, int32_t* num_points_out, int batch,
+                        int max_points, int dim, int dtype, void* stream);
 
 /* ---- fused T-step rollout with in-kernel fixed policies -------------------------------- */
 int hk_rollout(const hk_rollout_desc* desc, void* stream);

@@ -37,13 +37,18 @@ def lib() -> C.CDLL:
         protos = {}
         for name, (res, args) in A.PROTOTYPES.items():
             if name in ("hk_abi_version", "hk_strerror", "hk_has_fast_path", "hk_rollout_workspace_bytes",
-                        "hk_rollout_reduce_counts", "hk_rollout_values") or name.startswith("hk_search_"):
-                continue  # launch plumbing / restated in oracle/search_oracle.py and np_oracle.rollout_postprocess
+                        "hk_rollout_reduce_counts", "hk_rollout_values", "hk_bin_group_games", "hk_bin_unit_games",
+                        "hk_generate_points_binned", "hk_bin_by_live_rows") or name.startswith("hk_search_"):
+                continue  # launch plumbing / restated in oracle/search_oracle.py and np_oracle.rollout_postprocess /
+                          # the binning's group geometry is the kernels' own: hko_bin_by_live_rows takes it as arguments
             args = list(args[:-1])  # no stream on the CPU
             protos["hko_" + name[3:]] = (res, args)
         A.bind(_lib, protos)
         _lib.hko_set_threads.restype = C.c_int
         _lib.hko_set_threads.argtypes = [C.c_int]
+        _lib.hko_bin_by_live_rows.restype = C.c_int
+        _lib.hko_bin_by_live_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, C.c_int]
     return _lib
 
 
@@ -270,4 +275,18 @@ def rollout_generated(batch: int, spec, steps: int, seed: int, *, max_value: int
     r.gen_max_value, r.gen_seed, r.gen_stages, r.episodes = max_value, seed if gen_seed is None else gen_seed, gen_stages, episodes
     _check(lib().hko_rollout(C.byref(r)))
     return p, rec
+
+
+def bin_by_live_rows(points: np.ndarray, group: int, unit: int):
+    """hk_bin_by_live_rows / hk_generate_points_binned's order (include/hironaka_hip.h): the games of every group of
+    `group` consecutive games ranked widest first, equal games in their order; rank p of full group k goes to position
+    (p // unit) * F * unit + k * unit + p % unit (F full groups: the k-th units of all groups lie together), a partial
+    last group is ranked in place.  Returns (re-ordered points, game ids, live rows per position)."""
+    p = np.ascontiguousarray(points)
+    b, m, d = p.shape
+    out = np.empty_like(p)
+    ids = np.empty(b, dtype=np.int32)
+    npts = np.empty(b, dtype=np.int32)
+    _check(lib().hko_bin_by_live_rows(_ptr(p), _ptr(out), _ptr(ids), _ptr(npts), b, m, d, _hk_dtype(p), group, unit))
+    return out, ids, npts
 

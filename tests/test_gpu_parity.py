@@ -571,7 +571,12 @@ def test_reordered_batch_with_game_ids_rolls_out_like_the_original(spec):
     idn = host(ids)
     assert sorted(idn.tolist()) == list(range(p0.shape[0]))
     cnt = (p0[:, :, 0] >= 0).sum(1)
-    assert np.array_equal(host(binned), p0[idn]) and np.all(np.diff(cnt[idn]) <= 0)
+    assert np.array_equal(host(binned), p0[idn])
+    group, rot = ops.bin_group(m, d)
+    if group:  # the on-device order: local to groups, strata of sixteen (include/hironaka_hip.h) -- the oracle's
+        assert np.array_equal(idn, CO.bin_by_live_rows(p0, group, rot)[1])
+    else:      # the tensor library's global stable sort
+        assert np.all(np.diff(cnt[idn]) <= 0)
     fields = ("host_class", "axis", "done", "reward", "game_length")
     for hp, ap in ((A.HK_HOST_RANDOM, A.HK_AGENT_RANDOM), (A.HK_HOST_RANDOM, A.HK_AGENT_RANDOM_LEGAL),
                    (A.HK_HOST_ZEILLINGER, A.HK_AGENT_CHOOSE_FIRST)):
@@ -594,6 +599,38 @@ def test_reordered_batch_with_game_ids_rolls_out_like_the_original(spec):
                     for k in rec:
                         assert np.array_equal(host(got[k]), want[k]), (k, hp, ap, T, fl)
                     assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"])
+
+
+@pytest.mark.parametrize("spec", [(10, 3), (20, 3), (20, 4), (50, 4)])
+def test_binning_on_the_device_matches_oracle(spec):
+    """hk_bin_by_live_rows / hk_generate_points_binned (ABI 4): the order local to groups of games (widest first, equal
+    games in their order, the k-th sixteen games of all full groups together, a partial last group in place) equals
+    the oracle's on batches of one game, one wave, one group +- one game, several groups and a ragged tail; the
+    generator's binned output is the binned output of the plain generator; the counts per position."""
+    m, d = spec
+    group, rot = ops.bin_group(m, d)
+    assert group in (64, 256) and rot == 16
+    for b in (1, 15, 16, 17, group - 1, group, group + 1, 3 * group, 3 * group + 77):
+        p0 = CO.generate_points(b, m, d, 20, 13, 5)
+        want_p, want_ids, want_np = CO.bin_by_live_rows(p0, group, rot)
+        got_p, got_ids, got_np = ops.bin_by_live_rows(dev(p0.copy()), want_num_points=True)
+        assert np.array_equal(host(got_ids), want_ids), b
+        assert np.array_equal(host(got_p), want_p) and np.array_equal(host(got_np), want_np), b
+        gen_p, gen_ids, gen_np = ops.generate_points_binned(b, m, d, 20, 13, game_offset=5, want_num_points=True)
+        assert np.array_equal(host(gen_ids), want_ids) and np.array_equal(host(gen_p), want_p), b
+        assert np.array_equal(host(gen_np), want_np), b
+    # states with holes in the middle, rescaled values, other stage subsets, torch semantics
+    p0 = CO.generate_points(2 * group + 9, m, d, 20, 3)
+    p0[::3] = CO.rollout(p0[::3], 3, 8, record=False)[0]
+    want_p, want_ids, _ = CO.bin_by_live_rows(p0, group, rot)
+    got_p, got_ids = ops.bin_by_live_rows(dev(p0.copy()))
+    assert np.array_equal(host(got_ids), want_ids) and np.array_equal(host(got_p), want_p)
+    for kw, st, sem in ((dict(rescale=True), A.HK_STAGE_NEWTON | A.HK_STAGE_REPOSITION | A.HK_STAGE_RESCALE, "jax"),
+                        (dict(reposition=False), A.HK_STAGE_NEWTON, "torch")):
+        raw = CO.generate_points(group + 40, m, d, 9, 2, stages=st, flags=CO.flags_of(sem=sem))
+        want_p, want_ids, _ = CO.bin_by_live_rows(raw, group, rot)
+        gen_p, gen_ids = ops.generate_points_binned(group + 40, m, d, 9, 2, flags=ops.make_flags(sem), **kw)
+        assert np.array_equal(host(gen_ids), want_ids) and np.array_equal(host(gen_p), want_p), kw
 
 
 @pytest.mark.parametrize("spec", [(20, 3), (10, 3), (4, 3), (8, 4), (20, 4), (50, 4)])
