@@ -55,26 +55,41 @@ __device__ inline void shift_game(T* p, int m, int d, const T* c, int axis, T pa
   }
 }
 
+// (operation for operation oracle/hko_impl.inc: reposition_game -- comparisons included, so that non-finite entries, which
+// only this exact path ever sees, come out as the restatement's do: under JAX semantics an unavailable entry stands in as
+// the column's maximum, a NaN minimum compares false with 0 and is subtracted, _jax_ops.py:114-120)
 template <typename T>
 __device__ inline void reposition_game(T* p, int m, int d, T pad, unsigned flags) {
   const unsigned sem = flags & HK_SEM_MASK;
   for (int k = 0; k < d; ++k) {
-    // minimum over the entries >= 0 of this column
-    bool have = false;
-    T mn = (T)0;
-    for (int i = 0; i < m; ++i) {
-      const T v = p[i * d + k];
-      if (v >= (T)0 && (!have || v < mn)) {
-        mn = v;
-        have = true;
+    if (sem == HK_SEM_JAX) {
+      T colmax = p[k];
+      for (int i = 1; i < m; ++i)
+        if (p[i * d + k] > colmax) colmax = p[i * d + k];
+      T mn = (p[k] >= (T)0) ? p[k] : colmax;
+      for (int i = 1; i < m; ++i) {
+        const T v = (p[i * d + k] >= (T)0) ? p[i * d + k] : colmax;
+        if (v < mn) mn = v;
       }
-    }
-    // JAX: a column whose minimum is <= 0 (or that has no available entry, where the stand-in
-    // maximum is negative) is returned untouched (_jax_ops.py:121)
-    if (sem == HK_SEM_JAX && (!have || mn <= (T)0)) continue;
-    for (int i = 0; i < m; ++i) {
-      const T v = p[i * d + k];
-      p[i * d + k] = (v >= (T)0) ? v - mn : pad;
+      if (mn <= (T)0) continue;  // column untouched (_jax_ops.py:121)
+      for (int i = 0; i < m; ++i) {
+        const T v = p[i * d + k];
+        p[i * d + k] = (v >= (T)0) ? v - mn : pad;
+      }
+    } else {
+      bool have = false;
+      T mn = (T)0;
+      for (int i = 0; i < m; ++i) {
+        const T v = p[i * d + k];
+        if (v >= (T)0 && (!have || v < mn)) {
+          mn = v;
+          have = true;
+        }
+      }
+      for (int i = 0; i < m; ++i) {
+        const T v = p[i * d + k];
+        p[i * d + k] = (v >= (T)0) ? v - mn : pad;
+      }
     }
   }
 }
@@ -83,7 +98,10 @@ __device__ inline void reposition_game(T* p, int m, int d, T pad, unsigned flags
 // Sequential application is equivalent to the reference's simultaneous masks: a duplicate is
 // decided against the first (never modified) occurrence, and "P_j <= P_i componentwise" is a
 // strict partial order on the de-duplicated rows, so every removed row is also dominated by a
-// surviving (minimal) row and dropping it early changes nothing.
+// surviving (minimal) row and dropping it early changes nothing.  The test is the reference's SUBTRACTION
+// (P_i - P_j >= 0, _jax_ops.py:55-56), not a comparison: inf - inf is NaN, so two rows that are both infinite in a
+// coordinate do not dominate each other -- on such rows the relation is still transitive (a row dominated through an
+// infinite coordinate is dominated by finite ones only), so the sequential form keeps equalling the simultaneous one.
 template <typename T>
 __device__ inline void newton_game(T* p, int m, int d, T pad, unsigned flags) {
   const unsigned sem = flags & HK_SEM_MASK;
@@ -109,7 +127,7 @@ __device__ inline void newton_game(T* p, int m, int d, T pad, unsigned flags) {
       bool dom = true;  // row j available and P_j <= P_i
       for (int k = 0; k < d; ++k) {
         const T vj = p[j * d + k];
-        dom &= (vj >= (T)0) & (p[i * d + k] >= vj);
+        dom &= (vj >= (T)0) & (p[i * d + k] - vj >= (T)0);
       }
       removed = dom;
     }
