@@ -345,7 +345,7 @@ def main():
         return r
 
     # ---- the one-launch-per-step variants (rank 0's shard, N=1 only) ----------------------------------------------
-    single = api = dense = legal = large = config3 = config5 = overlapped = unbinned = None
+    single = api = dense = legal = large = config3 = config5 = overlapped = unbinned = generate = compute_rho = None
     if extras:
         def episode_stepwise():
             for t in range(EPISODE):
@@ -462,33 +462,74 @@ def main():
                                     "note": "two lanes per game, the pair test split over them (duo_kernel<..., ZEIL>)"}
         done_count.zero_()
 
-        # ---- the same episodes on the batch BINNED by live rows (the round-2 review's proposal: a wave then holds
-        # games of one size), with the permutation as game ids (every game keeps its policy stream) and without -------
-        def binned_episodes(**ids):
-            if args.no_binned:
-                return None
+        # ---- state generation (generate_pts; 8(d) keeps it out of `value`), the batch binned by live
+        # rows on the device (round 4: one launch, local to groups of games; hk_rollout_desc.game_ids keeps every game's
+        # policy stream), and the episode on the binned batch ------------------------------------------------------------
+        gen_buf = torch.empty_like(fresh)
 
-            def run():
-                for _ in range(BLOCK):
-                    ops.rollout(state, EPISODE, SEED, initial=binned, defer_counts=True, workspace=count_ws, **ids, **kw)
-                ops.reduce_counts(count_ws, done_count, b, EPISODE, (m, d))
-            med, _, _ = timed_replays(capture(run).replay, MIN_SECTION_S)
-            return med / BLOCK * 1e6
-        us_ids, us_pos = binned_episodes(game_ids=game_ids), binned_episodes()
-        torch.cuda.synchronize()
-        tb0 = time.perf_counter()
-        for _ in range(20):
-            ops.bin_by_live_rows(fresh)
-        torch.cuda.synchronize()
-        unbinned = None if args.no_binned else {"us_per_episode_with_game_ids": us_ids, "us_per_episode_positions_as_ids": us_pos,
-                    "binning_us_per_batch": (time.perf_counter() - tb0) / 20 * 1e6,
-                    "note": "secondary, NOT the headline: ops.bin_by_live_rows (hk_get_num_points + a stable sort + a "
-                            "gather; binning_us_per_batch is its host-timed cost) orders the games by live rows, "
-                            "hk_rollout_desc.game_ids keeps every game's policy stream (results identical game by "
-                            "game; the id load delays the action window by ~0.6 us); without ids the binned batch is "
-                            "a batch of its own.  One episode gains less than the binning costs: for batches rolled "
-                            "out many times or binned off the clock"}
+        def us_per(fn, reps=BLOCK):
+            med, _, _ = timed_replays(capture(lambda: [fn(i) for i in range(reps)]).replay, MIN_SECTION_S)
+            return med / reps * 1e6
+        gen_us = us_per(lambda i: ops.generate_points(b, m, d, MAX_VALUE, seed=42 + i, out=gen_buf))
+        raw_us = us_per(lambda i: ops.generate_points(b, m, d, MAX_VALUE, seed=42 + i, out=gen_buf, newton=False,
+                                                      reposition=False))
+        generate = {"us_per_batch": gen_us, "raw_draws_us_per_batch": raw_us, "games_per_s": b / gen_us * 1e6,
+                    "roofline": hbm_roofline(gen_us / 1e6, b * m * d * 4, prof.get("generate_bytes_per_launch"),
+                                             f"hk::quadgen_kernel<{m}, {d}> at {b} games"),
+                    "note": "hk_generate_points: randint[0, max_value) -> Newton polytope -> reposition (jax/util.py:385-392), "
+                            "four lanes per game; algorithmic bytes = the state written once (nothing is read); "
+                            "raw_draws = the same launch without the stages (Philox + the store)"}
+        unbinned = None
+        if not args.no_binned:
+            genb_us = us_per(lambda i: ops.generate_points_binned(b, m, d, MAX_VALUE, 42 + i, out=gen_buf))
+            bin_us = us_per(lambda i: ops.bin_by_live_rows(fresh, out=gen_buf))
+
+            def binned_episodes(**ids):
+                def run():
+                    for _ in range(BLOCK):
+                        ops.rollout(state, EPISODE, SEED, initial=binned, defer_counts=True, workspace=count_ws, **ids, **kw)
+                    ops.reduce_counts(count_ws, done_count, b, EPISODE, (m, d))
+                med, _, _ = timed_replays(capture(run).replay, MIN_SECTION_S)
+                return med / BLOCK * 1e6
+            us_ids, us_pos = binned_episodes(game_ids=game_ids), binned_episodes()
+            group, unit = ops.bin_group(m, d)
+            unbinned = {"generate_us_per_batch": gen_us, "generate_binned_us_per_batch": genb_us,
+                        "binning_us_per_batch": bin_us, "us_per_episode_with_game_ids": us_ids,
+                        "us_per_episode_positions_as_ids": us_pos, "group_games": group, "unit_games": unit,
+                        "note": "secondary, NOT the headline: hk_generate_points_binned (the generator bins before it "
+                                "stores: one launch) / hk_bin_by_live_rows (an existing batch: one launch; round 3 used "
+                                "hk_get_num_points + a stable sort + a gather of the tensor library, 85 us host-timed) "
+                                "order the games by live rows inside groups of `group_games`, the k-th `unit_games` of "
+                                "all groups together; hk_rollout_desc.game_ids keeps every game's policy stream "
+                                "(results identical game by game).  At (20,3) the order gains nothing; it pays at "
+                                "(50,4): see config3_dim4_50points"}
         done_count.zero_()
+
+        # ---- JAXTrainer.compute_rho's loop (jax_trainer.py:502-555: draw a batch, roll it out, keep the histogram) as ONE
+        # launch: the batch is drawn inside the kernel, nothing but the per-step counts leaves it, E loops per launch --------
+        rho_ws = ops.rollout_workspace(b, EPISODE, (m, d))
+        E = 10
+        rho_one = us_per(lambda i: ops.rollout_generated(b, (m, d), EPISODE, SEED, max_value=MAX_VALUE, episodes=E,
+                                                         defer_counts=True, workspace=rho_ws, **kw), reps=2) / E
+        rho_each = us_per(lambda i: ops.rollout_generated(b, (m, d), EPISODE, SEED + i, max_value=MAX_VALUE, episodes=1,
+                                                          defer_counts=True, workspace=rho_ws, **kw))
+
+        def rho_round3(i):
+            ops.generate_points(b, m, d, MAX_VALUE, seed=SEED + i, out=gen_buf)
+            ops.rollout(gen_buf, EPISODE, SEED + i, defer_counts=True, workspace=rho_ws, **kw)
+        rho_two = us_per(rho_round3)
+        ops.reduce_counts(rho_ws, done_count, b, EPISODE, (m, d))
+        done_count.zero_()
+        compute_rho = {"us_per_loop": rho_one, "loops_per_launch": E, "us_per_loop_one_launch_each": rho_each,
+                       "us_per_loop_generate_then_rollout": rho_two, "env_steps_per_s": b * EPISODE / rho_one * 1e6,
+                       "traffic_per_loop": prof.get("rho_loop_bytes_per_launch"),
+                       "note": "rollout.compute_rho by name = ONE hk_rollout launch (hk_rollout_desc.gen_max_value, "
+                               "episodes, points = NULL): `us_per_loop` per batch of 65 536 games INCLUDING its generation "
+                               "(Philox + the dense first Newton pass), E loops back to back inside the launch -- a wave "
+                               "starts its next episode when its own games are finished (the in-kernel form of "
+                               "`overlapped_episodes`); us_per_loop_generate_then_rollout = the round-3 form of the loop "
+                               "(hk_generate_points + hk_rollout: ~47 MB of state traffic per loop)"}
+        del gen_buf
 
         # ---- two independent episodes in flight (NOT the headline number): the launch of 65 536 games ends with its
         # slowest waves (mean wave lifetime 15 us inside a 21 us kernel, scripts/probe_timeline.py) and nothing
@@ -572,8 +613,14 @@ def main():
                                   MIN_SECTION_S)
         r3, _, _ = timed_replays(capture(roll3).replay, MIN_SECTION_S)
         c3, _, _ = timed_replays(capture(lambda: out3.copy_(fresh3)).replay, MIN_SECTION_S)
-        binned3 = None
-        if not args.no_binned:  # the same episode on the batch binned by live rows, game ids keep the streams
+        def us3(fn, reps=2):
+            med, _, _ = timed_replays(capture(lambda: [fn(i) for i in range(reps)]).replay, MIN_SECTION_S)
+            return med / reps * 1e6
+        gen3 = us3(lambda i: ops.generate_points(b3, m3, d3, MAX_VALUE, seed=42 + i, out=out3))
+        binned3 = genb3 = bin3 = rho3 = rho3_two = None
+        if not args.no_binned:  # the same episode on the batch binned by live rows on the device, game ids keep the streams
+            genb3 = us3(lambda i: ops.generate_points_binned(b3, m3, d3, MAX_VALUE, 42 + i, out=out3))
+            bin3 = us3(lambda i: ops.bin_by_live_rows(fresh3, out=out3))
             b3_pts, b3_ids = ops.bin_by_live_rows(fresh3)
 
             def roll3_binned():
@@ -582,6 +629,19 @@ def main():
             rb3, _, _ = timed_replays(capture(roll3_binned).replay, MIN_SECTION_S)
             binned3 = rb3 * 1e6
             del b3_pts, b3_ids
+            ws3 = ops.rollout_workspace(b3, EPISODE, (m3, d3))
+            rho3 = us3(lambda i: ops.rollout_generated(b3, (m3, d3), EPISODE, SEED, max_value=MAX_VALUE, episodes=4,
+                                                       defer_counts=True, workspace=ws3), reps=1) / 4
+
+            def rho3_round3(i):
+                ops.generate_points(b3, m3, d3, MAX_VALUE, seed=SEED + i, out=out3)
+                ops.rollout(out3, EPISODE, SEED + i, defer_counts=True, workspace=ws3)
+            rho3_two = us3(rho3_round3)
+            ops.reduce_counts(ws3, dc3, b3, EPISODE, (m3, d3))
+        # the other operators of the shape (SURVEY f-2, f-4, a15): observation features, Zeillinger's class
+        feat3 = us3(lambda i: ops.get_features(fresh3, out=out3.reshape(b3, m3 * d3)))
+        featt3 = us3(lambda i: ops.get_features_torch(fresh3))
+        zeil3 = us3(lambda i: ops.zeillinger(fresh3))
         config3 = {"workload": f"dim={d3}, max_points={m3}, batch={b3} (BASELINE configs[2])",
                    "hk_step_us": s3 / 5 * 1e6, "hk_step_env_steps_per_s": b3 * 5 / s3,
                    "roofline": hbm_roofline(s3 / 5, b3 * bs3, kernel="hk_step at (50,4) x 262144 from generate_pts states"),
@@ -590,6 +650,16 @@ def main():
                    "state_copy_us": c3 * 1e6,
                    "fused_rollout_us_per_episode": r3 * 1e6, "fused_env_steps_per_s": b3 * EPISODE / r3,
                    "fused_rollout_binned_by_live_rows_us_per_episode": binned3,
+                   "fused_binned_env_steps_per_s": (b3 * EPISODE / binned3 * 1e6) if binned3 else None,
+                   "generate_us_per_batch": gen3,
+                   "generate_frac_of_hbm_peak": b3 * m3 * d3 * 4 / gen3 / 1e3 / HBM_PEAK_GBS,
+                   "generate_binned_us_per_batch": genb3, "binning_us_per_batch": bin3,
+                   "compute_rho_us_per_loop": rho3, "compute_rho_us_per_loop_generate_then_rollout": rho3_two,
+                   "get_features_us": feat3, "get_features_torch_us": featt3, "zeillinger_us": zeil3,
+                   "binned_note": "the order of hk_generate_points_binned (groups of 64 games, strata of 16) with the "
+                                  "permutation as game ids: the default route for batches of this shape that are rolled "
+                                  "out from memory -- generate + bin is one launch; the fused compute_rho loop draws its "
+                                  "batches in the kernel",
                    "algorithmic_bytes_per_env_step": bs3}
         del fresh3, out3, state3, dense3
 
@@ -705,6 +775,7 @@ def main():
                                   "all-gather (every rank receives all ranks' final states), max over ranks; it is "
                                   "inside `value`")
         for key, val in (("single_step", single), ("boundary_step", api), ("single_step_dense", dense),
+                         ("generate", generate), ("compute_rho", compute_rho),
                          ("binned_by_live_rows", unbinned), ("overlapped_episodes", overlapped), ("large_batch", large),
                          ("legal_axis_torch_list_semantics", legal),
                          ("config3_dim4_50points", config3), ("config5_mcts_simulate", config5)):

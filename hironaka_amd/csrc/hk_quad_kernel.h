@@ -340,9 +340,7 @@ constexpr int kQuadDppSlots = 8;
 
 template <int CW, int R, int D, int NB, int CSEG>
 struct QuadLdsPairs {
-  // `rm`: bit s = my slot s is removed (a bit per slot in ONE register: as a running float minimum per slot the verdicts
-  // took NB registers through the whole loop -- the (50,4) rollout kernels sit at their 168-register budget)
-  static __device__ __forceinline__ void run(const float (&q)[R * D], uint32_t& rm, uint32_t (&jmask)[2],
+  static __device__ __forceinline__ void run(const float (&q)[R * D], float (&acc)[NB], uint32_t (&jmask)[2],
                                              const float* cmine, int j, int rows_end) {
     constexpr int r0 = kQuad * (CSEG - 1);
     if (rows_end <= r0) return;
@@ -364,19 +362,19 @@ struct QuadLdsPairs {
         qd_extrema<D>(pj, &q[s * D], t, u);
         const bool below = (s < CSEG - 1) || (r0 + j < row);  // my row 4s + j lies below row j
         jdead |= below && (u >= 0.0f);
-        rm |= (below && u < 0.0f && t <= 0.0f) ? (1u << s) : 0u;
+        acc[s] = hk_fmin(acc[s], (below && u < 0.0f) ? t : 1.0f);
       }
       const uint32_t bit = jdead ? (1u << (row & 31)) : 0u;
       if (row < 32) jmask[0] |= bit;
       else jmask[1] |= bit;
     }
-    if constexpr (CSEG < NB) QuadLdsPairs<CW, R, D, NB, CSEG + 1>::run(q, rm, jmask, cmine, j, rows_end);
+    if constexpr (CSEG < NB) QuadLdsPairs<CW, R, D, NB, CSEG + 1>::run(q, acc, jmask, cmine, j, rows_end);
   }
 };
 
 template <int M, int CW, int R, int D, int NB>
 __device__ __forceinline__ void qd_newton_lds(float (&q)[R * D], float* cmine, int j, int rows_end) {
-  static_assert(kQuad * NB <= 64 && NB <= 32, "verdicts on row j travel as 64 bits, those on my slots as 32");
+  static_assert(kQuad * NB <= 64, "verdicts on row j travel as 64 bits");
   // (opaque: hoisted out of a rollout's step loops, the segments' start addresses -- one register each, live through the
   // whole staircase -- were part of what the (50,4) rollout kernels spilled)
   asm volatile("" : "+v"(cmine));
@@ -393,16 +391,18 @@ __device__ __forceinline__ void qd_newton_lds(float (&q)[R * D], float* cmine, i
     }
   }
   wave_lds_fence();
-  uint32_t rm = 0u;
+  float acc[NB];
+#pragma unroll
+  for (int s = 0; s < NB; ++s) acc[s] = INFINITY;
   uint32_t jmask[2] = {0u, 0u};
-  QuadLdsPairs<CW, R, D, NB, 1>::run(q, rm, jmask, cmine, j, rows_end);
+  QuadLdsPairs<CW, R, D, NB, 1>::run(q, acc, jmask, cmine, j, rows_end);
   jmask[0] = q_or(jmask[0]);
   jmask[1] = q_or(jmask[1]);
 #pragma unroll
   for (int s = 0; s < NB; ++s) {
     const int i = kQuad * s + j;
     const bool by_lower = ((i < 32 ? jmask[0] : jmask[1]) >> (i & 31)) & 1u;
-    const bool removed = ((rm >> s) & 1u) || by_lower;  // (a hole stays a hole either way)
+    const bool removed = acc[s] <= 0.0f || by_lower;  // (a hole stays a hole either way)
 #pragma unroll
     for (int k = 0; k < D; ++k) q[s * D + k] = removed ? INFINITY : q[s * D + k];
   }

@@ -49,6 +49,9 @@ __device__ __forceinline__ void qg_rows(float (&q)[RD], float* stage, uint64_t g
   using GG = QuadGenGeom<M, D>;
   constexpr int R = GG::R;
   static_assert(RD == R * D, "slots per lane x dim");
+  // (opaque: inside a rollout's episode loop the first Philox round of every block -- it depends on the lane alone -- and
+  // the staging addresses were hoisted out of the loop and kept in registers through every episode: spills)
+  asm volatile("" : "+v"(j), "+v"(gi));
   float* mine = stage + gi * GG::kStage;
   if (gen_short(max_value)) {  // (wave-uniform)
 #pragma unroll
@@ -239,11 +242,14 @@ __device__ __forceinline__ void qg_newton_packed(float (&q)[R * D], uint32_t* sc
   else if (s1 <= 10) qg_packed_level1<(R < 10 ? R : 10)>(sc, vd, np1, rows, j, lane);
   else qg_packed_level1<R>(sc, vd, np1, rows, j, lane);
   wave_lds_fence();
+  // the survivors' floats from their packed words (v_cvt_f32_ubyteN: exact): q[] is written here and nowhere read since
+  // the packing -- its R * D registers are free during the whole test (inside a rollout kernel's 168-register budget
+  // they were what spilled)
 #pragma unroll
   for (int s = 0; s < R; ++s) {
     const bool kept = ((lm >> s) & 1u) && vd[((lm >> s) & 1u) ? rk[s] : 0] == 0;
 #pragma unroll
-    for (int k = 0; k < D; ++k) q[s * D + k] = kept ? q[s * D + k] : INFINITY;
+    for (int k = 0; k < D; ++k) q[s * D + k] = kept ? (float)((w[s] >> (8 * k)) & 0xFFu) : INFINITY;
   }
   wave_lds_fence();  // (the scratch is the game's image again)
 }

@@ -735,7 +735,11 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   }
   // (non-temporal: the final state is written once and not read again by the launch -- kept out of the XCD's L2 it
   // leaves the next episode's initial states there, hk_duo_kernel.h)
-  if (publish) quad_slab_store<M, D, !REC>(region, (float*)prm.out + g0 * G::N, ngames, lane);
+  if (publish) {
+    float* outp = (float*)prm.out;
+    if constexpr (GEN) asm volatile("" : "+s"(outp));  // (inside the episode loop: the chunks' 64-bit addresses are not hoisted out of it)
+    quad_slab_store<M, D, !REC>(region, outp + g0 * G::N, ngames, lane);
+  }
   // the finished-game counts: games whose first finished step is <= s, for every s (a finished game stays finished)
   if (prm.count_ws) add_length_counts(prm.count_ws + blockIdx.x, prm.count_stride, 0, nsteps, leader, length, lane);
   if (last_episode) break;

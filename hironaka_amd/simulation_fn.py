@@ -59,11 +59,14 @@ def get_evaluation_loop(role: str, policy_fn: Callable, opponent_fn: Callable, r
         root = RootFnOutput(prior_logits=policy_prior, value=value_prior, embedding=root_states)
         key, subkey = _split(key)
         if use_graph:
-            # one capture per launch shape; it is tied to the identity of the argument tuples (a hipGraph replays with
-            # the tensors it was captured with): other tuples REPLACE it -- no unbounded growth when a trainer hands
-            # over fresh parameter objects every optimiser step (updating the parameter tensors in place keeps it)
+            # one capture per launch shape; it is tied to the identity of the parameter OBJECTS inside the argument
+            # tuples (a hipGraph replays with the tensors it was captured with) -- not of the tuples themselves, which
+            # callers such as functional.mcts_wrapper build afresh on every call: keyed by the tuples' ids a search was
+            # re-captured on every opponent move and never replayed.  Other parameter objects REPLACE the capture -- no
+            # unbounded growth when a trainer hands over fresh ones every optimiser step (updating the tensors in place
+            # keeps it); the cache entry keeps the objects alive, so an id cannot be recycled while it is the key.
             sig = (tuple(root_states.shape), root_states.dtype, root_states.device, invalid_actions is not None)
-            ids = (id(role_fn_args), id(opponent_fn_args))
+            ids = (tuple(map(id, role_fn_args)), tuple(map(id, opponent_fn_args)))
             if sig not in captured or captured[sig][0] != ids:
                 captured.pop(sig, None)
                 captured[sig] = (ids, CapturedSearch((role_fn_args, opponent_fn_args), subkey, root, recurrent_fn,

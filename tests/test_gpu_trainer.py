@@ -84,6 +84,33 @@ def test_simulate_modes_shapes_and_sanity(role):
                for x, y in zip(exp, again))
 
 
+def test_captured_searches_are_replayed_not_recaptured(monkeypatch):
+    """simulate(use_mcts_policy=True): the opponent answers with a search of its own, whose argument TUPLES are built
+    afresh on every call (functional.mcts_wrapper) around the SAME parameter objects.  The capture cache is keyed by the
+    objects: over two simulate calls every (role, tree kind, shape) is captured once and replayed from then on (keyed by
+    the tuples' ids it re-captured a search on every opponent move)."""
+    from hironaka_amd import search as S
+    built = []
+    real = S.CapturedSearch
+
+    class Counting(real):
+        def __init__(self, *a, **kw):
+            built.append(1)
+            super().__init__(*a, **kw)
+
+    monkeypatch.setattr(S, "CapturedSearch", Counting)
+    import hironaka_amd.simulation_fn as SF
+    monkeypatch.setattr(SF, "CapturedSearch", Counting)
+    t = make_trainer(use_graph=True)
+    first = t.simulate(3, "host", use_mcts_policy=True)
+    n_first = len(built)
+    again = t.simulate(3, "host", use_mcts_policy=True)
+    assert len(built) == n_first, (n_first, len(built))          # the second call replays every graph
+    assert n_first <= 4, n_first                                   # ... and the first captured each search once
+    assert all(torch.equal(torch.nan_to_num(x, neginf=-1e30), torch.nan_to_num(y, neginf=-1e30))
+               for x, y in zip(first, again))
+
+
 def test_simulate_baseline_config5_at_size():
     """BASELINE configs[4]: batch 8192, 32 simulations per move, 20 moves, dim 3, 20 points, one hipGraph per
     search.  Checked: shapes, rollout_sanity_tests, value range, and that consecutive observations of every game are
