@@ -187,18 +187,6 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(v) for v in t.tolist()]
 
-    def gather_final_states():
-        """the trainer boundary: every rank ends up with all B*world final states"""
-        if not distributed:
-            return state
-        # HK_BENCH_GATHER=direct: the fully-connected point-to-point variant (distributed.all_gather_games_direct);
-        # default: RCCL's own all-gather
-        direct = os.environ.get("HK_BENCH_GATHER", "rccl") == "direct"
-        shard = hkdist.Shard(rank * b, b, world * b)
-        if backend == "nccl":
-            return hkdist.all_gather_games(state, shard, direct=direct, validate=False)
-        return hkdist.all_gather_games(state.cpu(), shard, direct=direct, validate=False)
-
     def timed_replays(replay, min_seconds):
         """`replay()` enqueues one unit of work (graph replays) on the current stream.  Estimate its duration,
         run an untimed clock warm-up as long as the measurement, then time SEGMENTS segments of n units each
@@ -252,36 +240,60 @@ def main():
     launches_per_region = n_full + (1 if rem else 0)
     reduce_every = max(1, BLOCK // max(1, launches_per_region))  # regions between two counter reductions
     g_episode = capture(lambda: episodes_deferred(1))
+    gather_events = []
     if distributed:
-        # one rank-local graph per region; the trainer-boundary gather follows EVERY region (an
-        # episode, then the all-gather of its final states), timed with its own events
+        # One rank-local graph per region, and after EVERY region the trainer-boundary all-gather of its final states
+        # (an episode, then the gather).  Episodes are independent, so the gather of region i does
+        # not sit on the launch stream: the regions alternate between two state buffers and hkdist.GatherPipeline runs
+        # the collective on a side stream behind an event while region i + 1 computes (`value`); the same regions
+        # without any gather (`value_without_gather`) and with the gather serialised on the launch stream and timed with
+        # its own events (`gather_us`) are measured next to it.
         group = 1
-        g_region = capture(one_region)
-        g_region_reduce = capture(lambda: (one_region(), reduce_counts()))
+        states = [state, torch.empty_like(state)]
+
+        def region_into(buf):
+            def run():
+                for n_ep, n_st in ((n_full, EPISODE), (1 if rem else 0, rem)):
+                    for _ in range(n_ep):
+                        ops.rollout(buf, n_st, SEED, defer_counts=True, workspace=count_ws, **head, **kw)
+            return run
+        g_region = [capture(region_into(buf)) for buf in states]
+        g_region_reduce = [capture(lambda buf=buf: (region_into(buf)(), reduce_counts())) for buf in states]
+        direct = os.environ.get("HK_BENCH_GATHER", "rccl") == "direct"
+        shard = hkdist.Shard(rank * b, b, world * b)
+        pipe = hkdist.GatherPipeline(shard, depth=2, direct=direct)
+
+        def boundary(buf):  # (gloo rehearsal: the states are staged through host memory)
+            return buf if backend == "nccl" else buf.cpu()
     else:
         # ONE graph holds `group` regions + the counter reduction, so a short region (the driver's --steps 20 is a
         # single 12-23 us launch) does not pay a graph replay of its own: the launches of a group run back to back
         group = reduce_every
         g_group = capture(lambda: ([one_region() for _ in range(group)], reduce_counts()))
-    gather_events = []
 
-    def run_groups(count, start=0, timed=False):
-        """count x group regions (every region = exactly K env steps)"""
+    def run_groups(count, start=0, gather="pipelined"):
+        """count x group regions (every region = exactly K env steps); N > 1: the gather of every region's final states
+        `pipelined` behind the next region, `serial` on the launch stream (timed with its own events), or `none`"""
         out = None
         for r in range(start, start + count):
             if not distributed:
                 g_group.replay()
                 continue
-            (g_region_reduce if (r + 1) % reduce_every == 0 else g_region).replay()
-            if timed:
+            p = r & 1
+            pipe.wait(tickets[p])  # the last gather that reads this buffer is done before the region overwrites it
+            (g_region_reduce[p] if (r + 1) % reduce_every == 0 else g_region[p]).replay()
+            if gather == "pipelined":
+                tickets[p] = pipe.submit(boundary(states[p]))
+            elif gather == "serial":
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                out = gather_final_states()
+                out = hkdist.all_gather_games(boundary(states[p]), shard, direct=direct, validate=False)
                 e1.record()
                 gather_events.append((e0, e1))
-            else:
-                out = gather_final_states()
+        if distributed and gather == "pipelined" and count:
+            out = pipe.result()
         return out
+    tickets = [None, None]
 
     # ---- warm-up (untimed): W steps, then a clock warm-up as long as the measurement ----------------------------
     for _ in range(max(1, W // EPISODE)):
@@ -290,45 +302,66 @@ def main():
     g_reduce.replay()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(SEGMENTS + 1)]
-    run_groups(1)
-    torch.cuda.synchronize()
-    ev[0].record()
-    run_groups(3)
-    ev[1].record()
-    torch.cuda.synchronize()
-    est = max(ev[0].elapsed_time(ev[1]) / 1e3 / 3, 1e-7)  # seconds per group
-    per_seg = max(1, math.ceil(MIN_TIMED_S / SEGMENTS / est))
-    if distributed:
-        per_seg = math.ceil(per_seg / reduce_every) * reduce_every
-    per_seg = int(max_over_ranks([per_seg])[0])  # the same on every rank
-    repeats = SEGMENTS * per_seg * group  # regions in the timed bracket
-    run_groups(SEGMENTS * per_seg)
-    barrier()
+
+    def timed_pass(gather):
+        """an untimed estimate + clock warm-up, then SEGMENTS x per_seg groups inside one barrier + synchronize bracket;
+        returns (wall seconds, median seconds per region, regions, last gathered tensor)"""
+        run_groups(2, gather=gather)
+        torch.cuda.synchronize()
+        ev[0].record()
+        run_groups(4, gather=gather)
+        ev[1].record()
+        torch.cuda.synchronize()
+        est = max(ev[0].elapsed_time(ev[1]) / 1e3 / 4, 1e-7)  # seconds per group
+        per_seg = max(1, math.ceil(MIN_TIMED_S / SEGMENTS / est))
+        if distributed:
+            per_seg = math.ceil(per_seg / (2 * reduce_every)) * 2 * reduce_every  # (whole reduce periods, both buffers)
+        per_seg = int(max_over_ranks([per_seg])[0])  # the same on every rank
+        run_groups(SEGMENTS * per_seg, gather=gather)
+        barrier()
+        done_count.zero_()
+        barrier()
+        t0 = time.perf_counter()
+        ev[0].record()
+        last = None
+        for sgm in range(SEGMENTS):
+            got = run_groups(per_seg, sgm * per_seg, gather=gather)
+            last = got if got is not None else last
+            ev[sgm + 1].record()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        wall = max_over_ranks([time.perf_counter() - t0])[0]
+        seg = sorted(max_over_ranks([ev[i].elapsed_time(ev[i + 1]) / 1e3 for i in range(SEGMENTS)]))
+        median_region = 0.5 * (seg[SEGMENTS // 2 - 1] + seg[SEGMENTS // 2]) / (per_seg * group)
+        return wall, median_region, SEGMENTS * per_seg * group, last
 
     # ---- the timed region: `repeats` x exactly K steps ----------------------------------------------------------
-    done_count.zero_()
-    barrier()
-    t0 = time.perf_counter()
-    ev[0].record()
-    final_states = state
-    for s in range(SEGMENTS):
-        got = run_groups(per_seg, s * per_seg, timed=True)
-        final_states = got if got is not None else final_states
-        ev[s + 1].record()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    elapsed = max_over_ranks([time.perf_counter() - t0])[0]
-    seg_s = max_over_ranks([ev[s].elapsed_time(ev[s + 1]) / 1e3 for s in range(SEGMENTS)])
+    elapsed, median_region_s, repeats, final_states = timed_pass("pipelined")
+    final_states = state if final_states is None else final_states
     assert final_states.shape[0] == world * b
-    seg_sorted = sorted(seg_s)
-    median_region_s = 0.5 * (seg_sorted[SEGMENTS // 2 - 1] + seg_sorted[SEGMENTS // 2]) / (per_seg * group)
-    gather_us = None
-    if gather_events:
-        gs = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in gather_events)
-        gather_us = max_over_ranks([gs[len(gs) // 2]])[0]
     timed_episodes = repeats * n_full
     finished = int(done_count[EPISODE].item()) // timed_episodes if timed_episodes else 0
+    gather_us = value_without_gather = overlap_hidden = None
+    if distributed:
+        # the pipelined result equals the serial gather of the same buffer
+        last_buf = states[(SEGMENTS * (repeats // SEGMENTS) - 1) & 1]
+        serial = hkdist.all_gather_games(boundary(last_buf), shard, direct=direct, validate=False)
+        torch.cuda.synchronize()
+        assert torch.equal(serial, final_states), "the pipelined gather differs from the serial one"
+        t_nog, _, reps_nog, _ = timed_pass("none")
+        value_without_gather = world * b * K * reps_nog / t_nog
+        run_groups(2 * reduce_every, gather="serial")
+        gather_events.clear()
+        run_groups(16 * reduce_every, gather="serial")
+        torch.cuda.synchronize()
+        gs = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in gather_events)
+        gather_us = max_over_ranks([gs[len(gs) // 2]])[0]
+        # what a region costs with the gather on the launch stream (compute + gather) against what it cost pipelined
+        region_alone_us = t_nog / reps_nog * 1e6
+        pipelined_us = elapsed / repeats * 1e6
+        hideable = min(region_alone_us, gather_us)
+        overlap_hidden = max(0.0, min(1.0, (region_alone_us + gather_us - pipelined_us) / hideable)) if hideable > 0 else None
 
     extras = world == 1 and b == BATCH and not args.no_single_step
     bytes_step = algorithmic_bytes_per_step(m, d)
@@ -760,7 +793,8 @@ def main():
                             f"{EPISODE} env steps per launch",
                 "parallelism": f"{world} x independent game shards" + (
                     f"; after EVERY {K}-step region one all-gather of the final states of all ranks "
-                    f"({os.environ.get('HK_BENCH_GATHER', 'rccl')}), inside the timed region" if distributed else ""),
+                    f"({os.environ.get('HK_BENCH_GATHER', 'rccl')}), pipelined behind the next region on a side "
+                    f"stream, inside the timed region" if distributed else ""),
                 "launch": f"hipGraph replays: one rollout kernel per episode, one counter reduce per "
                           f"{reduce_every * launches_per_region} episodes, {group} region(s) per graph; the K-step "
                           f"region repeated {repeats}x inside one barrier+synchronize bracket",
@@ -771,9 +805,15 @@ def main():
         if gather_us is not None:
             out["gather_us"] = gather_us
             out["gather_bytes_per_rank"] = int(world * b * m * d * 4)
-            out["gather_note"] = ("median over the timed regions of the HIP-event time around the trainer-boundary "
-                                  "all-gather (every rank receives all ranks' final states), max over ranks; it is "
-                                  "inside `value`")
+            out["value_without_gather"] = value_without_gather
+            out["overlap_hidden_frac"] = overlap_hidden
+            out["gather_check"] = "the pipelined gather's result equals the serial gather of the same states"
+            out["gather_note"] = ("`value`: after EVERY region its final states are all-gathered over the ranks, on a "
+                                  "side stream behind the next region (hkdist.GatherPipeline, two state buffers); "
+                                  "`value_without_gather`: the same regions alone; `gather_us`: the gather serialised "
+                                  "on the launch stream, HIP-event time, median, max over ranks; overlap_hidden_frac = "
+                                  "(region + gather - pipelined region) / min(region, gather).  A 20 us episode cannot "
+                                  "hide a gather of (N - 1) x 15.7 MB: at N > 1 `value` is the gather's rate")
         for key, val in (("single_step", single), ("boundary_step", api), ("single_step_dense", dense),
                          ("generate", generate), ("compute_rho", compute_rho),
                          ("binned_by_live_rows", unbinned), ("overlapped_episodes", overlapped), ("large_batch", large),

@@ -126,10 +126,99 @@ def all_gather_games_direct(local: torch.Tensor, shard: Shard, rows_per_game: in
     return out
 
 
-def all_gather_rollout(rollout: Sequence[torch.Tensor], shard: Optional[Shard] = None, rows_per_game: int = 1):
+def all_gather_rollout(rollout: Sequence[torch.Tensor], shard: Optional[Shard] = None, rows_per_game: int = 1,
+                       validate: bool = True):
     """(obs, policy, value) of each rank -> the full batch on every rank (trainer boundary).  `rows_per_game`:
-    simulate()'s tensors are flattened to one row per game and move ([B * T, ...]: T rows per game)."""
-    return tuple(all_gather_games(x, shard, rows_per_game=rows_per_game) for x in rollout)
+    simulate()'s tensors are flattened to one row per game and move ([B * T, ...]: T rows per game).
+    The local sizes are checked ONCE, collectively, on the first tensor (one int32 all-reduce + a host synchronisation,
+    `validate`); the tensors of one rollout share their leading dimension, which is asserted locally."""
+    rollout = tuple(rollout)
+    if not rollout:
+        return rollout
+    rows = rollout[0].shape[0]
+    if any(x.shape[0] != rows for x in rollout):
+        raise ValueError("the tensors of a rollout share their leading dimension")
+    first = all_gather_games(rollout[0], shard, rows_per_game=rows_per_game, validate=validate)
+    if shard is None:  # (the sizes were exchanged for the first tensor: a Shard-less gather of the rest exchanges them again)
+        return (first,) + tuple(all_gather_games(x, None, rows_per_game=rows_per_game) for x in rollout[1:])
+    return (first,) + tuple(all_gather_games(x, shard, rows_per_game=rows_per_game, validate=False)
+                            for x in rollout[1:])
+
+
+class GatherPipeline:
+    """The trainer-boundary gather BEHIND the next episode.  Episodes are independent, so the all-gather of episode i's
+    final states need not sit between episode i and episode i + 1 on the launch stream (where its latency is the whole
+    N > 1 curve): `submit` hands the states to a side stream behind an event and returns at once; the producer runs
+    episode i + 1 into its OTHER buffer meanwhile; `result` makes the current stream wait for a gather.  The reference's
+    counterpart is the host-side use of per-device results after the pmapped loop (jax_trainer.py:513,533-534).
+
+    Double-buffered by the CALLER: a tensor handed to `submit` must not be overwritten before `depth` further submits
+    (bench.py alternates two state buffers; `copy=True` stages a private copy instead: one device copy per gather).
+    Backend nccl (RCCL): the collective is enqueued on the side stream.  Host tensors / gloo (the CPU rehearsal): the
+    gather runs at `submit` (there is no stream to overlap with) -- the same results, the same protocol."""
+
+    def __init__(self, shard: Shard, rows_per_game: int = 1, depth: int = 2, direct: bool = False):
+        self.shard, self.rows_per_game, self.depth, self.direct = shard, int(rows_per_game), int(depth), bool(direct)
+        self._out = [None] * self.depth
+        self._done = [None] * self.depth
+        self._stage = [None] * self.depth
+        self._side = None
+        self._n = 0
+
+    def submit(self, local: torch.Tensor, copy: bool = False) -> int:
+        slot = self._n % self.depth
+        self._n += 1
+        if not local.is_cuda:
+            self._out[slot] = all_gather_games(local, self.shard, direct=self.direct, rows_per_game=self.rows_per_game,
+                                               validate=False)
+            self._done[slot] = None
+            return self._n - 1
+        cur = torch.cuda.current_stream(local.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=local.device)
+        if copy:
+            if self._stage[slot] is None or self._stage[slot].shape != local.shape:
+                self._stage[slot] = torch.empty_like(local)
+            if self._done[slot] is not None:
+                cur.wait_event(self._done[slot])  # the slot's previous gather has read its staging buffer
+            self._stage[slot].copy_(local)
+            local = self._stage[slot]
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            out = all_gather_games(local, self.shard, direct=self.direct, rows_per_game=self.rows_per_game, validate=False)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        self._out[slot], self._done[slot] = out, done
+        return self._n - 1
+
+    def result(self, ticket: Optional[int] = None) -> torch.Tensor:
+        """the gathered tensor of `ticket` (default: the latest submit); the current stream waits for it.  Valid until
+        `depth` further submits."""
+        ticket = self._n - 1 if ticket is None else ticket
+        if ticket < 0 or ticket < self._n - self.depth or ticket >= self._n:
+            raise ValueError(f"ticket {ticket} is not among the last {self.depth} submits")
+        slot = ticket % self.depth
+        if self._done[slot] is not None:
+            torch.cuda.current_stream(self._out[slot].device).wait_event(self._done[slot])
+        return self._out[slot]
+
+    def wait(self, ticket: Optional[int]) -> None:
+        """the current stream waits until the gather of `ticket` has READ its input (before the producer overwrites that
+        buffer).  A ticket older than `depth` submits is covered by the later gather of its slot (the side stream runs
+        them in order)."""
+        if ticket is None or ticket < 0 or ticket >= self._n:
+            return
+        slot = ticket % self.depth
+        if self._done[slot] is not None and self._out[slot] is not None:
+            torch.cuda.current_stream(self._out[slot].device).wait_event(self._done[slot])
+
+    def drain(self) -> None:
+        """every submitted gather is finished when the current stream passes this point"""
+        for slot in range(self.depth):
+            if self._done[slot] is not None and self._out[slot] is not None:
+                torch.cuda.current_stream(self._out[slot].device).wait_event(self._done[slot])
 
 
 def all_reduce_counts(counts: torch.Tensor) -> torch.Tensor:

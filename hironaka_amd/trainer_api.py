@@ -84,6 +84,16 @@ def standin_mlp(in_dim: int, out_dim: int, seed: int, width: int = 256, device="
     return net, params
 
 
+class PendingRollout:
+    """simulate(..., overlap_gather=True): the gathered (obs, target_policy, target_value), still travelling"""
+
+    def __init__(self, pipes, tickets):
+        self._pipes, self._tickets = pipes, tickets
+
+    def result(self):
+        return tuple(pipe.result(t) for pipe, t in zip(self._pipes, self._tickets))
+
+
 class HipTrainer:
     """See the module docstring.  ``simulate`` / ``compute_rho`` / ``rollout_postprocess`` and the config keys follow
     JAXTrainer; the search loops behind ``simulate`` are built on first use, one per (role, kind of tree)."""
@@ -138,6 +148,7 @@ class HipTrainer:
         self.reward_fns = {role: get_reward_fn(role) for role in ("host", "agent")}
         self._sim_fns: Dict[Any, Callable] = {}   # (role, mcts opponent, unified tree) -> simulation
         self._fn_args: Dict[Any, Any] = {}        # (role, unified tree) -> (params objects, argument tuples)
+        self._gather_pipes = None                 # simulate(overlap_gather=True): one GatherPipeline per output tensor
         self.log: Dict[str, Any] = {}
 
     @staticmethod
@@ -196,7 +207,7 @@ class HipTrainer:
         return self._sim_fns[sim_key]
 
     # ---- jax_trainer.py:247-320 ------------------------------------------------------------------------------
-    def simulate(self, key: int, role: str, use_mcts_policy=False, use_unified_tree=False):
+    def simulate(self, key: int, role: str, use_mcts_policy=False, use_unified_tree=False, overlap_gather=False):
         """One batch of self-play: ``eval_batch_size`` games per process, ``max_length_game`` moves, every move
         chosen by a Gumbel-MuZero search of ``num_evaluations`` simulations over the HIP environment.
         Returns (obs [B*T, input_dim], target_policy [B*T, A], target_value [B*T]) with B the games of ALL
@@ -205,7 +216,11 @@ class HipTrainer:
 
         A search captured into a hipGraph (``use_graph``) replays with the parameter OBJECTS it was captured with:
         update ``host_params`` / ``agent_params`` in place (``tensor.copy_``) to keep the capture; assigning new
-        objects drops it and captures again on the next call (one capture per role and kind of tree is kept)."""
+        objects drops it and captures again on the next call (one capture per role and kind of tree is kept).
+
+        overlap_gather (more than one rank): return a `PendingRollout` instead -- the all-gather of the three tensors
+        runs on a side stream behind the next simulate's searches; `.result()` is the tuple above (valid until two
+        further simulate calls)."""
         opponent = self._opponent(role)
         sim_fn = self._sim_fn(role, use_mcts_policy, use_unified_tree)
         if use_unified_tree:
@@ -239,7 +254,15 @@ class HipTrainer:
         simulate_output = sim_fn(sim_key, root_state, cached[2], cached[3])
         out = self.rollout_postprocess(simulate_output, role, use_unified_tree)
         # (the rollout is flattened to [B * T, ...] rows: max_length_game rows per game)
-        return hkdist.all_gather_rollout(out, shard, rows_per_game=self.max_length_game)
+        if not overlap_gather or hkdist.world() == 1:
+            return hkdist.all_gather_rollout(out, shard, rows_per_game=self.max_length_game)
+        # the trainer-boundary gather on a side stream (hkdist.GatherPipeline): this call returns at once, the NEXT
+        # simulate's searches run while the three tensors travel; `.result()` makes the current stream wait for them
+        if self._gather_pipes is None:
+            self._gather_pipes = [hkdist.GatherPipeline(shard, rows_per_game=self.max_length_game, depth=2)
+                                  for _ in range(3)]
+        tickets = [pipe.submit(x.contiguous()) for pipe, x in zip(self._gather_pipes, out)]
+        return PendingRollout(self._gather_pipes, tickets)
 
     def rollout_postprocess(self, rollouts, role: str, use_unified_tree=True):
         """jax_trainer.py:558-592"""

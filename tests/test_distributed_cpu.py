@@ -54,6 +54,20 @@ def _worker(rank, world, port, total, tmpdir):
             raise AssertionError("an inconsistent local batch on ONE rank must raise on every rank")
         except ValueError:
             pass
+        # the pipelined gather (bench.py N > 1, HipTrainer.simulate): tickets, double buffering, the serial gather's result
+        pipe = D.GatherPipeline(shard, depth=2)
+        finals = [torch.from_numpy(CO.rollout(local, T, 7 + e, game_offset=shard.start, record=False)[0]) for e in range(3)]
+        tickets = [pipe.submit(f) for f in finals[:2]]
+        assert torch.equal(pipe.result(tickets[0]), D.all_gather_games(finals[0], shard))
+        tickets.append(pipe.submit(finals[2]))
+        assert torch.equal(pipe.result(), D.all_gather_games(finals[2], shard))
+        assert torch.equal(pipe.result(tickets[1]), D.all_gather_games(finals[1], shard))
+        try:
+            pipe.result(tickets[0])
+            raise AssertionError("a ticket older than the pipeline's depth is gone")
+        except ValueError:
+            pass
+        pipe.drain()
         counts = D.all_reduce_counts(torch.from_numpy(rec["done_count"].astype(np.int64)))
         if rank == 0:
             np.savez(os.path.join(tmpdir, "out.npz"), final=gathered.numpy(), obs=obs[0].numpy(), axis=obs[1].numpy(),

@@ -34,8 +34,14 @@ def check_line(out, n):
     r = out["roofline"]
     assert r["bound"] == "valu_issue" and (r["frac"] is None or 0 < r["frac"] <= 1)
     assert 0.9 < out["ms_per_step"] / out["ms_per_step_median"] < 1.5
-    if n > 1:  # the trainer-boundary gather follows every region and is timed with its own events
+    if n > 1:
+        # the trainer-boundary gather follows every region, pipelined behind the next one (`value`); the same regions
+        # alone, the gather serialised and timed with its own events, how much of it the pipeline hid, and the check that
+        # the pipelined result is the serial gather's
         assert out["gather_us"] > 0 and out["gather_bytes_per_rank"] == n * 65536 * 60 * 4
+        assert out["value_without_gather"] >= out["value"] > 0
+        assert 0.0 <= out["overlap_hidden_frac"] <= 1.0
+        assert "equals the serial gather" in out["gather_check"]
 
 
 def test_bench_single_rank_line():
