@@ -378,7 +378,7 @@ def main():
         return r
 
     # ---- the one-launch-per-step variants (rank 0's shard, N=1 only) ----------------------------------------------
-    single = api = dense = legal = large = config3 = config5 = overlapped = unbinned = generate = compute_rho = None
+    single = api = dense = legal = large = config3 = config5 = overlapped = unbinned = generate = compute_rho = persistent = None
     if extras:
         def episode_stepwise():
             for t in range(EPISODE):
@@ -563,6 +563,18 @@ def main():
                                "`overlapped_episodes`); us_per_loop_generate_then_rollout = the round-3 form of the loop "
                                "(hk_generate_points + hk_rollout: ~47 MB of state traffic per loop)"}
         del gen_buf
+
+        # ---- E episodes back to back inside ONE launch, from the states resident in memory (hk_rollout_desc.episodes): a
+        # wave starts its next episode when its own 16 games are finished -- no launch boundary, nothing waits for the
+        # launch's slowest waves (the in-kernel form of `overlapped_episodes`; `value` stays one episode at a time) ------
+        pers_us = us_per(lambda i: ops.rollout(state, EPISODE, SEED, initial=fresh, episodes=E, defer_counts=True,
+                                               workspace=rho_ws, **kw), reps=2) / E
+        ops.reduce_counts(rho_ws, done_count, b, EPISODE, (m, d))
+        done_count.zero_()
+        persistent = {"episodes_per_launch": E, "us_per_episode": pers_us, "env_steps_per_s": b * EPISODE / pers_us * 1e6,
+                      "note": "secondary: hk_rollout with episodes = E and the initial states in memory (episode e: seed "
+                              "+ e, every episode reads its slab again; four lanes per game); oracle-exact per episode "
+                              "(tests/test_gpu_parity.py::test_episodes_from_resident_states_match_oracle)"}
 
         # ---- two independent episodes in flight (NOT the headline number): the launch of 65 536 games ends with its
         # slowest waves (mean wave lifetime 15 us inside a 21 us kernel, scripts/probe_timeline.py) and nothing
@@ -815,7 +827,7 @@ def main():
                                   "(region + gather - pipelined region) / min(region, gather).  A 20 us episode cannot "
                                   "hide a gather of (N - 1) x 15.7 MB: at N > 1 `value` is the gather's rate")
         for key, val in (("single_step", single), ("boundary_step", api), ("single_step_dense", dense),
-                         ("generate", generate), ("compute_rho", compute_rho),
+                         ("generate", generate), ("compute_rho", compute_rho), ("persistent_episodes", persistent),
                          ("binned_by_live_rows", unbinned), ("overlapped_episodes", overlapped), ("large_batch", large),
                          ("legal_axis_torch_list_semantics", legal),
                          ("config3_dim4_50points", config3), ("config5_mcts_simulate", config5)):

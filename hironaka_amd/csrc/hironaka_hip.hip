@@ -492,9 +492,17 @@ static int params_from_rollout(const hk_rollout_desc* r, Params& prm) {
 
 // rollouts with generated initial states and / or several episodes as ONE launch (hk_quadroll_kernel.h: GEN)
 static bool use_quadroll_gen(const Params& prm, int dtype) {
-  if (prm.max_value <= 0) return false;
   Params probe = prm;
   probe.flags &= ~(unsigned)HK_FLAG_FORCE_FOUR_LANES;
+  if (prm.max_value <= 0) {
+    // episodes from the states in memory: where the waves of the launch are resident all at once (four per SIMD), a wave
+    // that starts its next episode early fills what the launch boundary left idle -- (20,3) x 65 536: 16.5 - 17.0 us per
+    // episode against 20.8 one launch each; beyond (131 072 games: 37 against 30 us; (50,4) x 262 144: 205 against
+    // 172 us, scripts/probe_persistent.py) the per-episode launches of the default kernels stay ahead
+    if (prm.flags & HK_FLAG_FORCE_FOUR_LANES) return quadroll_episodes_supported(probe, dtype);
+    const int64_t waves = ((int64_t)prm.batch + kQuadGames - 1) / kQuadGames;
+    return prm.m <= 32 && waves <= (int64_t)4 * device_simds() && quadroll_episodes_supported(probe, dtype);
+  }
   return quadroll_gen_supported(probe, dtype);
 }
 
@@ -506,7 +514,7 @@ static Params rollout_geometry(Params prm, int dtype) {
     prm.episodes = 1;
     if (!prm.in) prm.in = prm.out;
   }
-  return prm;
+  return prm;  // (the fused kernel's grid is quadroll_grid: within count_slots' bound whatever planned_grid picks)
 }
 
 uint64_t hk_rollout_workspace_bytes(const hk_rollout_desc* r) {
@@ -768,6 +776,13 @@ int hk_zeillinger(const void* points, int64_t stride, int32_t* class_out, int ba
     fast.mode = kModeStep;
     fast.pad = -1.0;
     if (fast_supported(fast, dtype)) return launch_fast(fast, (hipStream_t)stream);
+    // the large games on four lanes per game (hk_quadroll_kernel.h: the rollout kernel's prologue + pair loop): the JAX
+    // variant over contiguous 16-B aligned records
+    if (dtype == HK_F32 && max_points > 32 && (flags & HK_SEM_MASK) == HK_SEM_JAX && !(flags & HK_FLAG_FORCE_TEAM) &&
+        stride == (int64_t)max_points * dim && aligned(points, 16)) {
+      const int qs = launch_quadzeil(prm, (hipStream_t)stream);
+      if (qs != HK_ERR_UNSUPPORTED) return qs;
+    }
     if (team_supported(fast, dtype)) {
       const int ts = launch_team(fast, (hipStream_t)stream);
       if (ts != HK_ERR_UNSUPPORTED) return ts;

@@ -634,9 +634,55 @@ __device__ __forceinline__ void qd_ranks_stable(const float (&q)[R * D], int j, 
     rank[s] += qperm_i<kQuadUp3>(o1[s]) + qperm_i<kQuadUp2>(o2[s]);
 }
 
+// The same ranks for MANY slots per lane (more than kQuadDppSlots: states no Newton pass has thinned, (50,4) only): the
+// quad parks its rows at their compact ranks (4 s + lane) and every lane walks ALL the game's rows -- one broadcast read
+// per row -- against its own slots: a row comes first iff its key is greater, or equal with the lower compact rank.
+template <int M, int CW, int R, int D, int NB>
+__device__ __forceinline__ void qd_ranks_lds(const float (&q)[R * D], float* cmine, int j, int rows_end, bool coord0,
+                                             int (&rank)[R]) {
+#pragma unroll
+  for (int s = 0; s < R; ++s) rank[s] = 0;
+#pragma unroll
+  for (int s = 0; s < NB; ++s) {
+    if (kQuad * s + j < M) {
+      float* dst = cmine + (kQuad * s + j) * CW;
+      if constexpr (D == 4) {
+        *reinterpret_cast<vf4*>(dst) = vf4{q[s * D], q[s * D + 1], q[s * D + 2], q[s * D + 3]};
+      } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) dst[k] = q[s * D + k];
+      }
+    }
+  }
+  wave_lds_fence();
+#pragma nounroll
+  for (int row = 0; row < rows_end; ++row) {
+    float pj[D];
+    if constexpr (D == 4) {
+      const vf4 v = *reinterpret_cast<const vf4*>(cmine + row * CW);
+      pj[0] = v.x; pj[1] = v.y; pj[2] = v.z; pj[3] = v.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < D; ++k) pj[k] = cmine[row * CW + k];
+    }
+    const bool lj = pj[0] < INFINITY;
+    const int dj = row - j;  // (row < 4 s + j  <=>  dj < 4 s)
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+      bool gt, eq;
+      qd_key_cmp<D>(pj, &q[s * D], coord0, gt, eq);
+      rank[s] += (lj & (gt | (eq & (dj < kQuad * s)))) ? 1 : 0;
+    }
+  }
+  wave_lds_fence();  // (the compact image is written again afterwards)
+}
+
 // one transition on slots [0, NB) of the four lanes; returns the GAME's number of live rows.  `sorted` (list
 // semantics): the survivors are ranked right after the Newton stage, before a rescale could round two keys together.
-template <int M, int CW, int R, int D, int NB>
+// AUX: the kernel may be asked for the sorted observation features of many slots per lane (the run-time configured
+// kernels; the compiled configurations carry none of that code -- with it, even dead, the (50,4) step kernels went from
+// 236 registers to 256 and 372 B of scratch)
+template <int M, int CW, int R, int D, int NB, bool AUX = true>
 __device__ __forceinline__ int qd_stages(float (&q)[R * D], const float (&c)[D], int axis, int np, int j,
                                          unsigned flags, unsigned stages, float* cmine, int slots_end, bool sorted,
                                          int (&rank)[R], uint8_t* tsc = nullptr) {
@@ -653,15 +699,19 @@ __device__ __forceinline__ int qd_stages(float (&q)[R * D], const float (&c)[D],
       if (sorted) qd_ranks_first<R, D, NB>(q, rank);
   }
   if (stages & HK_STAGE_RESCALE) qd_rescale<R, D, NB>(q, flags);
-  if constexpr (NB <= kQuadDppSlots)  // the observation features are sorted AFTER their rescale
+  if constexpr (NB <= kQuadDppSlots) {  // the observation features are sorted AFTER their rescale
     if (stages & kStageFeatureSorts) qd_ranks_stable<R, D, NB>(q, j, (stages & kStageFeatureSort0) != 0, rank);
+  } else if constexpr (AUX) {
+    if (stages & kStageFeatureSorts)
+      qd_ranks_lds<M, CW, R, D, NB>(q, cmine, j, slots_end, (stages & kStageFeatureSort0) != 0, rank);
+  }
   int n = 0;
 #pragma unroll
   for (int r = 0; r < NB; ++r) n += (q[r * D] < INFINITY) ? 1 : 0;
   return q_sum(n);
 }
 
-template <int M, int D, int NB>
+template <int M, int D, int NB, bool AUX = true>
 struct QuadStagesFor {
   using G = QuadGeom<M, D>;
   static __device__ __forceinline__ int run(float (&q)[G::R * D], int smax, const float (&c)[D], int axis, int np,
@@ -669,11 +719,12 @@ struct QuadStagesFor {
                                             int (&rank)[G::R], uint8_t* tsc = nullptr) {
     const int slots_end = kQuad * smax < M ? kQuad * smax : M;
     if constexpr (NB >= G::R) {
-      return qd_stages<M, G::CW, G::R, D, G::R>(q, c, axis, np, j, flags, stages, cmine, slots_end, sorted, rank, tsc);
+      return qd_stages<M, G::CW, G::R, D, G::R, AUX>(q, c, axis, np, j, flags, stages, cmine, slots_end, sorted, rank, tsc);
     } else {
       if (smax <= NB)
-        return qd_stages<M, G::CW, G::R, D, NB>(q, c, axis, np, j, flags, stages, cmine, slots_end, sorted, rank, tsc);
-      return QuadStagesFor<M, D, G::next_bucket(NB)>::run(q, smax, c, axis, np, j, flags, stages, cmine, sorted, rank, tsc);
+        return qd_stages<M, G::CW, G::R, D, NB, AUX>(q, c, axis, np, j, flags, stages, cmine, slots_end, sorted, rank, tsc);
+      return QuadStagesFor<M, D, G::next_bucket(NB), AUX>::run(q, smax, c, axis, np, j, flags, stages, cmine, sorted, rank,
+                                                               tsc);
     }
   }
 };
@@ -1125,6 +1176,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void 
 
   // ---- large games: my slots (ranks j, j + 4, ... up to the wave's smax; slots past the game's live rows are holes)
   float q[G::kBig ? R * D : 1];
+  int rank[G::kBig ? R : 1];  // (the sorted observation features: a row's place in descending key order)
   if constexpr (G::kBig) {
 #pragma unroll
     for (int e = 0; e < R * D; ++e) q[e] = INFINITY;
@@ -1158,9 +1210,8 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void 
       return;
     }
 #endif
-    int rank[R];
     uint8_t* tsc = (G::kBig && M <= 64) ? tsc_all + (wave * kQuadGames + gi) * 128 : nullptr;
-    np = QuadStagesFor<M, D, 1>::run(q, smax, c, axis_in, np, j, flags, stages, cmine, false, rank, tsc);
+    np = QuadStagesFor<M, D, 1, HOT == kHotNone>::run(q, smax, c, axis_in, np, j, flags, stages, cmine, false, rank, tsc);
   }
   const bool done = np < 2;
   if (leader) {  // (scalar base + the lane's game index: no 64-bit address arithmetic per output)
@@ -1181,6 +1232,35 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void 
       return;
     }
 #endif
+    if (HOT == kHotNone && (stages & kStageFeatureSorts)) {
+      // ---- the observation features (hk_get_features / hk_get_features_torch): padding everywhere (every lane holds
+      // its rows in registers: the region is free), then every live row at its rank in descending key order ----------
+      wave_lds_fence();
+#pragma unroll
+      for (int it = 0; it < G::QL; ++it) {
+        const int qq = lane + it * kWave;
+        if (qq < kQuadGames * G::Q) {
+          if constexpr (G::W == 4) *reinterpret_cast<vf4*>(image + qq * 4) = vf4{pad, pad, pad, pad};
+          else if constexpr (G::W == 2) *reinterpret_cast<vf2*>(image + qq * 2) = vf2{pad, pad};
+          else image[qq] = pad;
+        }
+      }
+      wave_lds_fence();
+      unrolled_while<0, R>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if (s >= smax) return false;
+        if (q[s * D] < INFINITY) {
+          float* dst = mine + rank[s] * D;
+          if constexpr (D == 4) {
+            *reinterpret_cast<vf4*>(dst) = vf4{q[s * D], q[s * D + 1], q[s * D + 2], q[s * D + 3]};
+          } else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) dst[k] = q[s * D + k];
+          }
+        }
+        return true;
+      });
+    } else {
     // ---- large games: every slot in use returns its row (padding if it was removed) to its compact slot; the lane
     // that OWNS row i (it scanned it, it knows its rank) picks it up there and rebuilds its rows of the image: a dead
     // row is padding, as it was.  All reads of the compact image precede the first write of the slab image in the
@@ -1239,6 +1319,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void 
         }
       }
     }
+    }  // (not the sorted features)
   }
   wave_lds_fence();
 #ifdef HK_QUAD_PROBE
@@ -1378,7 +1459,6 @@ bool quad_ok_t(const Params& prm) {
 inline bool quad_supported(const Params& prm, int dtype) {
   if (dtype != HK_F32 || prm.mode != kModeStep) return false;
   if (prm.class_out) return false;
-  if ((prm.stages & kStageFeatureSorts) && prm.m * prm.d > 128) return false;  // (the large games: team kernel)
   if (prm.coords_kind == HK_COORDS_IN_RECORD) return false;
   if (prm.flags & (HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_TEAM | HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES))
     return false;

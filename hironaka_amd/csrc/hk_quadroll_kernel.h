@@ -333,9 +333,13 @@ __device__ __forceinline__ int qr_zeillinger(const float (&q)[R * D], float* cmi
 // the generator's stages on all slots -> one re-deal into the wave's bucket) and `episodes` of them run back to back --
 // episode e with seed + e and gen_seed + e, the counts accumulating; prm.out may be NULL (no final state is stored):
 // the whole loop of JAXTrainer.compute_rho (jax_trainer.py:502-555) without a byte of state traffic.
-template <int M, int D, int HOT, int WPB, bool REC = false, bool ZEIL = false, bool GEN = false>
+// EPI (without GEN): `episodes` of them from the states in memory -- every episode reads its slab again (hk_rollout_desc.
+// episodes with points_in); its own instantiation, so that the one-episode kernels carry no loop.
+template <int M, int D, int HOT, int WPB, bool REC = false, bool ZEIL = false, bool GEN = false, bool EPI = GEN>
 __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) void quadroll_kernel(
     const float* in0, int64_t in_stride0, int batch0, const Params prm) {
+  static_assert(!GEN || EPI, "generated initial states come with the episode loop");
+  static_assert(!EPI || !REC, "episodes back to back: plain rollouts");
   static_assert(!ZEIL || (!REC && HOT == kHotNone), "Zeillinger's host: plain rollouts, policies inside the loop");
   static_assert(!GEN || !REC, "generated initial states: plain rollouts");
   static_assert(!GEN || QuadRollGeom<M, D>::kRegion >= QuadGenGeom<M, D>::kRegion, "the generator's staging image lies in the region");
@@ -380,9 +384,12 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   const uint64_t gg_fill = prm.game_offset + (has_ids ? (uint64_t)raw_id : (uint64_t)(g0 + fill_game));
   const uint32_t wb_last = nsteps > 0 ? (step0 + (uint32_t)nsteps - 1u) >> 2 : step0 >> 2;
   float* mine = region + gi * G::N;
-  const int episodes = GEN ? prm.episodes : 1;
-  for (int ep = 0;; ++ep) {  // (GEN: `episodes` of them; the loop's body is not indented)
-  const bool last_episode = !GEN || ep + 1 >= episodes;
+  const int episodes = EPI ? prm.episodes : 1;
+  for (int ep = 0;; ++ep) {  // (EPI: `episodes` of them; the loop's body is not indented)
+  const bool last_episode = !EPI || ep + 1 >= episodes;
+  if constexpr (EPI && !GEN) {
+    if (ep > 0) quad_slab_load<M, D>(in0 + g0 * G::N, region, ngames, lane);  // (the first one went out above)
+  }
   uint64_t seed = prm.seed + (uint64_t)ep;
   asm volatile("" : "+s"(seed));
   // the first window of decoded actions, computed while the slab is in flight
@@ -469,6 +476,12 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
     float* cs = reinterpret_cast<float*>(act) + gi * D;
     const uint64_t gg = prm.game_offset + (has_ids ? (uint64_t)(uint32_t)__shfl((int)raw_id, gi) : (uint64_t)g);
     PolicyCache pcache;
+    if constexpr (ZEIL) {
+      if (prm.class_out) {  // hk_zeillinger: the class is the launch's only product
+        if (leader) (prm.class_out + g0)[(unsigned)gi] = zeillinger_game<float>(mine, prm.m, prm.d);
+        return;
+      }
+    }
     np = leader ? num_points<float>(mine, M, D) : 2;
     int length = (np < 2) ? 0 : -1;
     if (prm.count_ws) {
@@ -510,10 +523,14 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
           count_add(prm.count_ws + (size_t)(t + 1) * prm.count_stride + blockIdx.x, (uint32_t)__popcll(bd));
       }
     }
-    if (leader && prm.game_length_out) prm.game_length_out[g] = length;
+    if (leader && last_episode && prm.game_length_out) prm.game_length_out[g] = length;
     wave_lds_fence();
-    quad_slab_store<M, D>(region, (float*)prm.out + g0 * G::N, ngames, lane);
-    return;
+    if (last_episode) {
+      quad_slab_store<M, D>(region, (float*)prm.out + g0 * G::N, ngames, lane);
+      return;
+    }
+    wave_lds_fence();
+    continue;  // (EPI: the next episode reads its slab again)
   }
 
   // ---- compaction: every live row to the slot of its rank (the compact image lies over the slab image: every lane
@@ -569,6 +586,15 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   });
   wave_lds_fence();
   }  // (!GEN)
+  if constexpr (ZEIL && !GEN) {
+    if (prm.class_out) {
+      // hk_zeillinger (jax/players.py:55-109) as its own operator: Zeillinger's class of every game of the batch, the
+      // launch's only product -- the rollout kernel's prologue (slab in, live rows to their slots) and its pair loop
+      const int zc = qr_zeillinger<M, CW, R, D>(q, cmine, j, smax);
+      if (leader) (prm.class_out + g0)[(unsigned)gi] = zc;
+      return;
+    }
+  }
   if (!active) np = 2;  // never finished, never counted
   int length = (np < 2) ? 0 : -1;
 
@@ -613,8 +639,8 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   };
   int t = 0;
   bool stop = false;
-  // (GEN: the last episode's final state, if anybody asks)
-  const bool publish = !GEN || (last_episode && prm.out != nullptr);
+  // (EPI: the last episode's final state; GEN: if anybody asks)
+  const bool publish = !EPI || (last_episode && prm.out != nullptr);
   bool published = !publish;
   PolicyCache zcache;  // (ZEIL: the lane's own Philox block, one per four steps)
   const uint64_t gg_game =  // (ZEIL) the policy stream's index of the game this lane plays
@@ -737,7 +763,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   // leaves the next episode's initial states there, hk_duo_kernel.h)
   if (publish) {
     float* outp = (float*)prm.out;
-    if constexpr (GEN) asm volatile("" : "+s"(outp));  // (inside the episode loop: the chunks' 64-bit addresses are not hoisted out of it)
+    if constexpr (EPI) asm volatile("" : "+s"(outp));  // (inside the episode loop: the chunks' 64-bit addresses are not hoisted out of it)
     quad_slab_store<M, D, !REC>(region, outp + g0 * G::N, ngames, lane);
   }
   // the finished-game counts: games whose first finished step is <= s, for every s (a finished game stays finished)
@@ -797,6 +823,28 @@ int launch_quadroll_t(Params prm, hipStream_t stream) {
   return launch_status();
 }
 
+// hk_zeillinger on the rollout kernel's prologue + pair loop (JAX variant, contiguous records, the large games: the
+// small shapes' one-lane kernel is ahead there)
+template <int M, int D>
+int launch_quadzeil_t(Params prm, hipStream_t stream) {
+  constexpr int WPB = QuadRollGeom<M, D>::kWpb;
+  const int64_t waves = ((int64_t)prm.batch + kQuadGames - 1) / kQuadGames;
+  const unsigned grid = (unsigned)((waves + WPB - 1) / WPB);
+  prm.pad_f32 = -1.0f;
+  prm.pad = -1.0;
+  prm.mode = kModeRollout;
+  prm.steps = 0;
+  prm.host_policy = HK_HOST_ZEILLINGER;
+  prm.flags = HK_SEM_JAX;
+  prm.stages = 0;
+  prm.count_ws = nullptr;
+  prm.episodes = 1;
+  launch_prepare();
+  hipLaunchKernelGGL((quadroll_kernel<M, D, kHotNone, WPB, false, true>), dim3(grid), dim3(kWave * WPB), 0, stream,
+                     (const float*)prm.in, prm.in_stride, prm.batch, prm);
+  return launch_status();
+}
+
 inline bool quadroll_supported(const Params& prm, int dtype) {
   if (dtype != HK_F32 || !quadroll_request_ok(prm)) return false;
 #define HK_X(M_, D_) if (prm.m == M_ && prm.d == D_) return quad_ok_t<M_, D_>(prm);
@@ -818,6 +866,19 @@ int launch_quadroll_gen_t(Params prm, hipStream_t stream) {
   prm.pad_f32 = (float)prm.pad;
   launch_prepare();
   const int hot = fast_hot_config(prm);
+  if (prm.max_value <= 0) {  // episodes back to back from the states in memory (EPI without GEN)
+    if (prm.host_policy == HK_HOST_ZEILLINGER) return HK_ERR_UNSUPPORTED;
+    if (hot == kHotJax)
+      hipLaunchKernelGGL((quadroll_kernel<M, D, kHotJax, WPB, false, false, false, true>), dim3(grid), dim3(kWave * WPB), 0,
+                         stream, (const float*)prm.in, prm.in_stride, prm.batch, prm);
+    else if (hot == kHotTorch)
+      hipLaunchKernelGGL((quadroll_kernel<M, D, kHotTorch, WPB, false, false, false, true>), dim3(grid), dim3(kWave * WPB), 0,
+                         stream, (const float*)prm.in, prm.in_stride, prm.batch, prm);
+    else
+      hipLaunchKernelGGL((quadroll_kernel<M, D, kHotNone, WPB, false, false, false, true>), dim3(grid), dim3(kWave * WPB), 0,
+                         stream, (const float*)prm.in, prm.in_stride, prm.batch, prm);
+    return launch_status();
+  }
   if (prm.host_policy == HK_HOST_ZEILLINGER) {
     if constexpr (M > 32)
       hipLaunchKernelGGL((quadroll_kernel<M, D, kHotNone, WPB, false, true, true>), dim3(grid), dim3(kWave * WPB), 0, stream,
@@ -835,6 +896,14 @@ int launch_quadroll_gen_t(Params prm, hipStream_t stream) {
                        (const float*)nullptr, prm.in_stride, prm.batch, prm);
   }
   return launch_status();
+}
+
+// episodes back to back from the states in memory: plain rollouts the four-lane kernel serves, not Zeillinger's host
+inline bool quadroll_episodes_supported(const Params& prm, int dtype) {
+  if (prm.max_value > 0 || prm.episodes <= 1 || !prm.in || !prm.out) return false;
+  if (prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out) return false;
+  if (prm.host_policy == HK_HOST_ZEILLINGER) return false;
+  return quadroll_supported(prm, dtype);
 }
 
 inline bool quadroll_gen_supported(const Params& prm, int dtype) {
@@ -886,9 +955,17 @@ inline int64_t quadroll_grid(const Params& prm) {
 
 #ifndef HK_SPEC_TU
 #define HK_X(M_, D_) extern template int launch_quadroll_t<M_, D_>(Params, hipStream_t); \
-  extern template int launch_quadroll_gen_t<M_, D_>(Params, hipStream_t);
+  extern template int launch_quadroll_gen_t<M_, D_>(Params, hipStream_t);           \
+  extern template int launch_quadzeil_t<M_, D_>(Params, hipStream_t);
 HK_QUAD_SPECS(HK_X)
 #undef HK_X
+
+inline int launch_quadzeil(const Params& prm, hipStream_t stream) {
+#define HK_X(M_, D_) if (prm.m == M_ && prm.d == D_) return launch_quadzeil_t<M_, D_>(prm, stream);
+  HK_QUAD_SPECS(HK_X)
+#undef HK_X
+  return HK_ERR_UNSUPPORTED;
+}
 
 inline int launch_quadroll_gen(const Params& prm, hipStream_t stream) {
 #define HK_X(M_, D_) if (prm.m == M_ && prm.d == D_) return launch_quadroll_gen_t<M_, D_>(prm, stream);

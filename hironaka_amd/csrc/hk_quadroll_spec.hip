@@ -6,4 +6,5 @@
 namespace hk {
 static_assert(HK_SPEC_M * HK_SPEC_D > 0, "build with -DHK_SPEC_M=<max_points> -DHK_SPEC_D=<dim>");
 template int launch_quadroll_t<HK_SPEC_M, HK_SPEC_D>(Params, hipStream_t);
+template int launch_quadzeil_t<HK_SPEC_M, HK_SPEC_D>(Params, hipStream_t);
 }  // namespace hk

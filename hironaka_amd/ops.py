@@ -426,7 +426,7 @@ def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0
             done_count: Optional[torch.Tensor] = None,
             initial: Optional[torch.Tensor] = None, defer_counts: bool = False,
             workspace: Optional[torch.Tensor] = None,
-            game_ids: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+            game_ids: Optional[torch.Tensor] = None, episodes: int = 1) -> Dict[str, torch.Tensor]:
     """T fused steps with in-kernel policies (hk_rollout); `points` is updated IN PLACE.
     record: any of "obs", "host_class", "axis", "done", "reward", "game_length".
     done_count: optional uint64-as-int64 [steps+1] accumulator (zeroed by the caller).
@@ -436,7 +436,10 @@ def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0
         they accumulate over launches) and skip the reduce kernel; `reduce_counts` adds them to a
         done_count later -- one reduction for many rollouts.
     game_ids: optional int32 [B]: the policy stream of the game at position g is keyed by game_offset + game_ids[g]
-        (a batch re-ordered by `bin_by_live_rows` rolls out game by game as the original order would)."""
+        (a batch re-ordered by `bin_by_live_rows` rolls out game by game as the original order would).
+    episodes: E > 1 (needs `initial`, no per-step records): E episodes back to back, each from `initial` with seed + e;
+        the counts accumulate, `points` and game_length are the last episode's (hk_rollout_desc.episodes: one launch
+        where the four-lane kernel's waves are all resident, else one launch per episode inside the library)."""
     _require_device(points, "points")
     if points.dtype not in (torch.float32, torch.float64) or not points.is_contiguous() or points.dim() != 3:
         raise ValueError("rollout updates a contiguous [B, m, d] float32/float64 tensor in place")
@@ -488,6 +491,7 @@ def rollout(points: torch.Tensor, steps: int, seed: int, *, game_offset: int = 0
     r.padding_value, r.reward_sign = float(padding_value), float(reward_sign)
     r.batch, r.max_points, r.dim, r.dtype, r.steps = b, m, d, _TORCH2HK[points.dtype], steps
     r.host_policy, r.agent_policy, r.stages, r.flags = host_policy, agent_policy, stages, flags | _forced_flags
+    r.episodes = int(episodes)
     ws = workspace if defer_counts else _workspace(dev, lib().hk_rollout_workspace_bytes(C.byref(r)))
     r.workspace, r.workspace_bytes = ws.data_ptr(), ws.numel()
     with torch.cuda.device(dev):

@@ -832,7 +832,7 @@ def test_episodes_from_resident_states_match_oracle():
     for e in range(3):
         want_p, want = CO.rollout(p0, 20, 60 + e, record=False)
         total += want["done_count"]
-    for fam in (0, A.HK_FLAG_FORCE_FOUR_LANES, A.HK_FLAG_FORCE_ONE_LANE):
+    for fam in (0, A.HK_FLAG_FORCE_FOUR_LANES, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_TWO_LANES):
         P0, P = dev(p0.copy()), torch.empty((500, 20, 3), device="cuda")
         r = A.hk_rollout_desc()
         dc = torch.zeros(21, dtype=torch.int64, device="cuda")
@@ -849,6 +849,19 @@ def test_episodes_from_resident_states_match_oracle():
         assert np.array_equal(host(P), want_p), fam
         assert np.array_equal(host(dc).astype(np.uint64), total), fam
         assert np.array_equal(host(gl), want["game_length"]), fam
+    # through ops.rollout, with a game off the exact path in one wave (its episodes restart on the generic routines too)
+    p1 = p0.copy()
+    p1[37, 1, 0] = -1.0  # a partly padded row
+    tot = np.zeros(21, dtype=np.uint64)
+    for e in range(4):
+        want_p, want = CO.rollout(p1, 20, 9 + e, record=False)
+        tot += want["done_count"]
+    for fam in (0, A.HK_FLAG_FORCE_FOUR_LANES, A.HK_FLAG_FORCE_GENERIC):
+        P = torch.empty((500, 20, 3), device="cuda")
+        got = ops.rollout(P, 20, 9, initial=dev(p1.copy()), episodes=4, flags=fam, record=("game_length",))
+        assert np.array_equal(host(P), want_p), fam
+        assert np.array_equal(host(got["done_count"]).astype(np.uint64), tot), fam
+        assert np.array_equal(host(got["game_length"]), want["game_length"]), fam
 
 
 # ------------------------------------------------------------------------------------------
