@@ -512,30 +512,31 @@ def main():
                     "note": "hk_generate_points: randint[0, max_value) -> Newton polytope -> reposition (jax/util.py:385-392), "
                             "four lanes per game; algorithmic bytes = the state written once (nothing is read); "
                             "raw_draws = the same launch without the stages (Philox + the store)"}
-        unbinned = None
-        if not args.no_binned:
-            genb_us = us_per(lambda i: ops.generate_points_binned(b, m, d, MAX_VALUE, 42 + i, out=gen_buf))
-            bin_us = us_per(lambda i: ops.bin_by_live_rows(fresh, out=gen_buf))
+        genb_us = us_per(lambda i: ops.generate_points_binned(b, m, d, MAX_VALUE, 42 + i, out=gen_buf))
+        bin_us = us_per(lambda i: ops.bin_by_live_rows(fresh, out=gen_buf))
 
-            def binned_episodes(**ids):
-                def run():
-                    for _ in range(BLOCK):
-                        ops.rollout(state, EPISODE, SEED, initial=binned, defer_counts=True, workspace=count_ws, **ids, **kw)
-                    ops.reduce_counts(count_ws, done_count, b, EPISODE, (m, d))
-                med, _, _ = timed_replays(capture(run).replay, MIN_SECTION_S)
-                return med / BLOCK * 1e6
-            us_ids, us_pos = binned_episodes(game_ids=game_ids), binned_episodes()
-            group, unit = ops.bin_group(m, d)
-            unbinned = {"generate_us_per_batch": gen_us, "generate_binned_us_per_batch": genb_us,
-                        "binning_us_per_batch": bin_us, "us_per_episode_with_game_ids": us_ids,
-                        "us_per_episode_positions_as_ids": us_pos, "group_games": group, "unit_games": unit,
-                        "note": "secondary, NOT the headline: hk_generate_points_binned (the generator bins before it "
-                                "stores: one launch) / hk_bin_by_live_rows (an existing batch: one launch; round 3 used "
-                                "hk_get_num_points + a stable sort + a gather of the tensor library, 85 us host-timed) "
-                                "order the games by live rows inside groups of `group_games`, the k-th `unit_games` of "
-                                "all groups together; hk_rollout_desc.game_ids keeps every game's policy stream "
-                                "(results identical game by game).  At (20,3) the order gains nothing; it pays at "
-                                "(50,4): see config3_dim4_50points"}
+        def binned_episodes(**ids):
+            if args.no_binned:  # (profile passes: these launches share the headline kernel's name and grid)
+                return None
+
+            def run():
+                for _ in range(BLOCK):
+                    ops.rollout(state, EPISODE, SEED, initial=binned, defer_counts=True, workspace=count_ws, **ids, **kw)
+                ops.reduce_counts(count_ws, done_count, b, EPISODE, (m, d))
+            med, _, _ = timed_replays(capture(run).replay, MIN_SECTION_S)
+            return med / BLOCK * 1e6
+        us_ids, us_pos = binned_episodes(game_ids=game_ids), binned_episodes()
+        group, unit = ops.bin_group(m, d)
+        unbinned = {"generate_us_per_batch": gen_us, "generate_binned_us_per_batch": genb_us,
+                    "binning_us_per_batch": bin_us, "us_per_episode_with_game_ids": us_ids,
+                    "us_per_episode_positions_as_ids": us_pos, "group_games": group, "unit_games": unit,
+                    "note": "secondary, NOT the headline: hk_generate_points_binned (the generator bins before it "
+                            "stores: one launch) / hk_bin_by_live_rows (an existing batch: one launch; round 3 used "
+                            "hk_get_num_points + a stable sort + a gather of the tensor library, 85 us host-timed) "
+                            "order the games by live rows inside groups of `group_games`, the k-th `unit_games` of "
+                            "all groups together; hk_rollout_desc.game_ids keeps every game's policy stream "
+                            "(results identical game by game).  At (20,3) the order gains nothing; it pays at "
+                            "(50,4): see config3_dim4_50points"}
         done_count.zero_()
 
         # ---- JAXTrainer.compute_rho's loop (jax_trainer.py:502-555: draw a batch, roll it out, keep the histogram) as ONE
@@ -662,10 +663,10 @@ def main():
             med, _, _ = timed_replays(capture(lambda: [fn(i) for i in range(reps)]).replay, MIN_SECTION_S)
             return med / reps * 1e6
         gen3 = us3(lambda i: ops.generate_points(b3, m3, d3, MAX_VALUE, seed=42 + i, out=out3))
-        binned3 = genb3 = bin3 = rho3 = rho3_two = None
+        genb3 = us3(lambda i: ops.generate_points_binned(b3, m3, d3, MAX_VALUE, 42 + i, out=out3))
+        bin3 = us3(lambda i: ops.bin_by_live_rows(fresh3, out=out3))
+        binned3 = None
         if not args.no_binned:  # the same episode on the batch binned by live rows on the device, game ids keep the streams
-            genb3 = us3(lambda i: ops.generate_points_binned(b3, m3, d3, MAX_VALUE, 42 + i, out=out3))
-            bin3 = us3(lambda i: ops.bin_by_live_rows(fresh3, out=out3))
             b3_pts, b3_ids = ops.bin_by_live_rows(fresh3)
 
             def roll3_binned():
@@ -674,15 +675,15 @@ def main():
             rb3, _, _ = timed_replays(capture(roll3_binned).replay, MIN_SECTION_S)
             binned3 = rb3 * 1e6
             del b3_pts, b3_ids
-            ws3 = ops.rollout_workspace(b3, EPISODE, (m3, d3))
-            rho3 = us3(lambda i: ops.rollout_generated(b3, (m3, d3), EPISODE, SEED, max_value=MAX_VALUE, episodes=4,
-                                                       defer_counts=True, workspace=ws3), reps=1) / 4
+        ws3 = ops.rollout_workspace(b3, EPISODE, (m3, d3))
+        rho3 = us3(lambda i: ops.rollout_generated(b3, (m3, d3), EPISODE, SEED, max_value=MAX_VALUE, episodes=4,
+                                                   defer_counts=True, workspace=ws3), reps=1) / 4
 
-            def rho3_round3(i):
-                ops.generate_points(b3, m3, d3, MAX_VALUE, seed=SEED + i, out=out3)
-                ops.rollout(out3, EPISODE, SEED + i, defer_counts=True, workspace=ws3)
-            rho3_two = us3(rho3_round3)
-            ops.reduce_counts(ws3, dc3, b3, EPISODE, (m3, d3))
+        def rho3_round3(i):
+            ops.generate_points(b3, m3, d3, MAX_VALUE, seed=SEED + i, out=out3)
+            ops.rollout(out3, EPISODE, SEED + i, defer_counts=True, workspace=ws3)
+        rho3_two = us3(rho3_round3)
+        ops.reduce_counts(ws3, dc3, b3, EPISODE, (m3, d3))
         # the other operators of the shape (SURVEY f-2, f-4, a15): observation features, Zeillinger's class
         feat3 = us3(lambda i: ops.get_features(fresh3, out=out3.reshape(b3, m3 * d3)))
         featt3 = us3(lambda i: ops.get_features_torch(fresh3))

@@ -850,8 +850,17 @@ __device__ __forceinline__ void quad_actions_decode(const QuadActions<D, ACT>& a
 // FEAT: hk_step_features -- the observation features of the result (jax/util.py:172-214: [rescale] + rows in descending
 // key order, equal keys in row order) as a second output of the same launch: the bucket body has the result's rows in
 // registers, ranks them (qd_ranks_stable) and builds the sorted image in the compact region, which is free by then.
+// kHotSort (large games): the launches whose product is a sorted image and nothing else (hk_get_features /
+// hk_get_features_torch: [rescale] + the ranks) -- no step stages compiled in, so the kernel fits three waves per SIMD (it
+// waits for its slab most of its life: PMC at two waves, 2 190 VALU instructions inside 8 400 wave cycles) and needs no
+// scratch for the two-level test.
+constexpr int kHotSort = 3;
+template <int M, int D, int HOT>
+constexpr int quad_waves_per_simd() {
+  return (HOT == kHotSort && QuadGeom<M, D>::kBig) ? 3 : QuadGeom<M, D>::kWavesPerSimd;
+}
 template <int M, int D, int HOT, int WPB, int ACT, bool FEAT = false>
-__global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void quad_kernel(const float* in0, int64_t in_stride0, int batch0,
+__global__ __launch_bounds__(kWave * WPB, (quad_waves_per_simd<M, D, HOT>())) void quad_kernel(const float* in0, int64_t in_stride0, int batch0,
                                                            const Params prm) {
   using G = QuadGeom<M, D>;
   constexpr int R = G::R;
@@ -859,7 +868,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void 
   __shared__ __align__(16) float lds_all[WPB * G::kRegion];
   __shared__ float cbuf_all[WPB * kQuadGames * D];  // slow path only
   // large games: scratch of the two-level domination test (slot indices + verdicts, 2 x 64 bytes per game)
-  __shared__ __align__(16) uint8_t tsc_all[(G::kBig && M <= 64) ? WPB * kQuadGames * 128 : 16];
+  __shared__ __align__(16) uint8_t tsc_all[(G::kBig && M <= 64 && HOT != kHotSort) ? WPB * kQuadGames * 128 : 16];
   // the wave index as a scalar: the slab's addresses, the LDS region and the game count stay in SGPRs
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & (kWave - 1);
   float* image = lds_all + wave * G::kRegion;
@@ -880,7 +889,8 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void 
   float* mine = image + gi * G::N;
   const float pad = prm.pad_f32;
   const unsigned flags = (HOT == kHotJax) ? (unsigned)HK_SEM_JAX : prm.flags;
-  const unsigned stages = HOT ? (unsigned)(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON) : prm.stages;
+  const unsigned stages = (HOT == kHotSort) ? (prm.stages & ((unsigned)HK_STAGE_RESCALE | kStageFeatureSorts))
+                          : HOT ? (unsigned)(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON) : prm.stages;
   const float fill = ((flags & HK_SEM_MASK) == HK_SEM_JAX) ? -1.0f : pad;
   float c[D];
   int axis_in = -1;
@@ -1058,7 +1068,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void 
     const bool list_sorted = HOT == kHotNone && (stages & HK_STAGE_NEWTON) &&
                              ((flags & HK_SEM_MASK) == HK_SEM_LIST || (flags & HK_FLAG_COMPACT_SORTED));
     // ... or the observation features: rows in descending key order (hk_get_features / hk_get_features_torch)
-    const bool sorted = list_sorted || (HOT == kHotNone && (stages & kStageFeatureSorts));
+    const bool sorted = list_sorted || ((HOT == kHotNone || HOT == kHotSort) && (stages & kStageFeatureSorts));
 #ifdef HK_QUAD_PROBE
     float probe_acc = 0.0f;
 #endif
@@ -1210,8 +1220,9 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void 
       return;
     }
 #endif
-    uint8_t* tsc = (G::kBig && M <= 64) ? tsc_all + (wave * kQuadGames + gi) * 128 : nullptr;
-    np = QuadStagesFor<M, D, 1, HOT == kHotNone>::run(q, smax, c, axis_in, np, j, flags, stages, cmine, false, rank, tsc);
+    uint8_t* tsc = (G::kBig && M <= 64 && HOT != kHotSort) ? tsc_all + (wave * kQuadGames + gi) * 128 : nullptr;
+    np = QuadStagesFor<M, D, 1, HOT == kHotNone || HOT == kHotSort>::run(q, smax, c, axis_in, np, j, flags, stages, cmine,
+                                                                         false, rank, tsc);
   }
   const bool done = np < 2;
   if (leader) {  // (scalar base + the lane's game index: no 64-bit address arithmetic per output)
@@ -1232,7 +1243,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadGeom<M, D>::kWavesPerSimd)) void 
       return;
     }
 #endif
-    if (HOT == kHotNone && (stages & kStageFeatureSorts)) {
+    if ((HOT == kHotNone || HOT == kHotSort) && (stages & kStageFeatureSorts)) {
       // ---- the observation features (hk_get_features / hk_get_features_torch): padding everywhere (every lane holds
       // its rows in registers: the region is free), then every live row at its rank in descending key order ----------
       wave_lds_fence();
@@ -1397,6 +1408,13 @@ int launch_quad_w(Params prm, hipStream_t stream) {
       return HK_ERR_UNSUPPORTED;
     }
   }
+  if constexpr (QuadGeom<M, D>::kBig) {
+    // the sorted observation features of the large games: the instantiation without the step stages (three waves per SIMD)
+    if ((prm.stages & kStageFeatureSorts) && !(prm.stages & (HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON))) {
+      launch_quad_k<M, D, WPB, kHotSort, kActAny>(prm, grid, stream);
+      return launch_status();
+    }
+  }
   if (hot) {  // the JAX trainer's take_actions, with the trainers' action layouts compiled in
     switch (act) {
       case kActMaskF32AxisI32: launch_quad_k<M, D, WPB, kHotJax, kActMaskF32AxisI32>(prm, grid, stream); break;
@@ -1459,6 +1477,9 @@ bool quad_ok_t(const Params& prm) {
 inline bool quad_supported(const Params& prm, int dtype) {
   if (dtype != HK_F32 || prm.mode != kModeStep) return false;
   if (prm.class_out) return false;
+  // (the large games: the torch container's one-coordinate sort stays with the team kernel -- 117 us at (50,4) x 262 144
+  // against 144 us here; the observation features are ahead here: 150 against 179 us)
+  if ((prm.stages & kStageFeatureSort0) && prm.m * prm.d > 128) return false;
   if (prm.coords_kind == HK_COORDS_IN_RECORD) return false;
   if (prm.flags & (HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_TEAM | HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES))
     return false;

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): rocprofv3 kernel trace + separate PMC passes of bench.py and a kernel trace of
 # the search workload; raw CSVs under gpurun_out/, then scripts/summarise_profile.py condenses them into profiles/.
-# usage: scripts/profile_round.sh r03
+# usage: scripts/profile_round.sh r04
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"

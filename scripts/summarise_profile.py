@@ -17,7 +17,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -29,6 +29,13 @@ STEP3 = (re.compile(r"quad_kernel<50, 4, 1, \d, 1(, false)*>"), "1048576")  # hk
 ROLL3 = (re.compile(r"quadroll_kernel<50, 4, 1, 1(, false)*>"), "1048576")  # fused rollout at (50,4) x 262 144
 # one in-kernel-policy step of 65 536 games (rollouts of <= 6 steps run on the four-lane kernel since round 3)
 SINGLE = (re.compile(r"quadroll_kernel<20, 3, 1, 4(, false)*>"), "262144")
+# round 4: the generator on four lanes, the compute_rho loop as one launch (initial states drawn in the kernel, counts
+# only: GEN), episodes back to back from resident states (EPI)
+GENERATE = (re.compile(r"quadgen_kernel<20, 3, 4>"), "262144")
+GENERATE3 = (re.compile(r"quadgen_kernel<50, 4, 4>"), "1048576")
+RHO = (re.compile(r"quadroll_kernel<20, 3, 1, 4, false, false, true, true>"), "262144")
+RHO3 = (re.compile(r"quadroll_kernel<50, 4, 1, 1, false, false, true, true>"), "1048576")
+EPISODES = (re.compile(r"quadroll_kernel<20, 3, 1, 4, false, false, false, true>"), "262144")
 
 
 def short(name):
@@ -156,7 +163,14 @@ out = {"source": f"rocprofv3 --pmc passes (separate runs), profiles/{tag}_pmc_su
        "boundary_step_wait_any_frac": (find(STEP, "", "SQ_WAIT_ANY") or 0) / (find(STEP, "", "SQ_WAVE_CYCLES") or 1),
        "config3_step_bytes_per_launch": traffic(STEP3),
        "config3_rollout_bytes_per_launch": traffic(ROLL3),
-       "config3_rollout_valu_insts_per_launch": find(ROLL3, "", "SQ_INSTS_VALU")}
+       "config3_rollout_valu_insts_per_launch": find(ROLL3, "", "SQ_INSTS_VALU"),
+       "generate_bytes_per_launch": traffic(GENERATE),
+       "generate_valu_insts_per_launch": find(GENERATE, "", "SQ_INSTS_VALU"),
+       "config3_generate_bytes_per_launch": traffic(GENERATE3),
+       "rho_loop_bytes_per_launch": traffic(RHO),
+       "rho_loop_valu_insts_per_launch": find(RHO, "", "SQ_INSTS_VALU"),
+       "config3_rho_loop_bytes_per_launch": traffic(RHO3),
+       "persistent_episodes_bytes_per_launch": traffic(EPISODES)}
 
 # ---- share of the GPU time of the search workload spent in this package's HIP kernels ----------------------------
 sstats = first("search/**/*kernel_stats.csv")
