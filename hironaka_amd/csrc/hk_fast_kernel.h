@@ -359,6 +359,7 @@ __device__ __forceinline__ void fast_policy_fill(uint8_t* act, uint64_t gg, uint
 // pays a fetch bubble for every taken branch, and the per-step tests of stages / flags / policies are ~15 %
 // of a fused rollout (measured: 43.5 -> 38.1 us per 20-step episode of 65 536 games).
 constexpr int kHotNone = 0, kHotJax = 1, kHotTorch = 2;
+constexpr int kHotList = 4;  // hk::quadroll_kernel: run-time configured, the state published sorted + compacted
 constexpr unsigned kHotTorchFlags = HK_SEM_TORCH | HK_FLAG_AXIS_NOOP_IF_INVALID | HK_FLAG_IGNORE_ENDED;
 
 template <int M, int D, int MODE, int HOT = kHotNone>

@@ -372,12 +372,13 @@ struct QuadLdsPairs {
   }
 };
 
-template <int M, int CW, int R, int D, int NB>
+// PIN (callers inside a step / episode loop): the parked rows' address is made opaque here -- hoisted out of a rollout's
+// step loops, the segments' start addresses (one register each, live through the whole staircase) were part of what the
+// (50,4) rollout kernels spilled
+template <int M, int CW, int R, int D, int NB, bool PIN = false>
 __device__ __forceinline__ void qd_newton_lds(float (&q)[R * D], float* cmine, int j, int rows_end) {
   static_assert(kQuad * NB <= 64, "verdicts on row j travel as 64 bits");
-  // (opaque: hoisted out of a rollout's step loops, the segments' start addresses -- one register each, live through the
-  // whole staircase -- were part of what the (50,4) rollout kernels spilled)
-  asm volatile("" : "+v"(cmine));
+  if constexpr (PIN) asm volatile("" : "+v"(cmine));
 #pragma unroll
   for (int s = 0; s < NB; ++s) {
     if (kQuad * s + j < M) {

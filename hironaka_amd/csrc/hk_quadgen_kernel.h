@@ -271,7 +271,7 @@ __device__ __forceinline__ int qg_stages(float (&q)[RD], int j, unsigned flags, 
   if ((stages & HK_STAGE_NEWTON) && !packed) {
     if constexpr (R > kQuadDppSlots) {
       if constexpr (TWO && QuadGenGeom<M, D>::kTwoLevel) qd_newton_two_level<M, G::CW, R, D, R>(q, cmine, tsc, j, M);
-      else qd_newton_lds<M, G::CW, R, D, R>(q, cmine, j, M);
+      else qd_newton_lds<M, G::CW, R, D, R, true>(q, cmine, j, M);
     } else {
       qd_newton<R, D, R>(q, j);
     }

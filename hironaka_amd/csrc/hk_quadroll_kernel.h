@@ -109,7 +109,7 @@ __device__ __forceinline__ int qr_stages(float (&q)[R * D], uint32_t cmask, int 
   if (stages & HK_STAGE_NEWTON) {
     if constexpr (NB > kQuadDppSlots) {
       const int slots_end = kQuad * smax < M ? kQuad * smax : M;
-      qd_newton_lds<M, CW, R, D, NB>(q, cmine, j, slots_end);
+      qd_newton_lds<M, CW, R, D, NB, true>(q, cmine, j, slots_end);
     } else {
       qd_newton<R, D, NB>(q, j);
     }
@@ -255,6 +255,71 @@ __device__ __forceinline__ void qr_build_image(const float (&q)[R * D], const ui
   wave_lds_fence();
 }
 
+// list semantics (_list_ops.py:25-41) for PLAIN rollouts: the state leaves the kernel sorted (descending lexicographic,
+// coordinate 0 first) and compacted -- ranked once, when it is published (between two Newton stages the order of the rows
+// changes nothing: hk_fast_kernel.h), before a pending rescale could round two keys together.  Rows are distinct after
+// a Newton stage.  Up to 8 slots per lane the ranks come through DPP (qd_ranks_first), beyond it from a rolled loop over
+// the rows parked by rank.
+template <int M, int CW, int R, int D, int NB>
+__device__ __forceinline__ void qr_build_sorted(float (&q)[R * D], float* region, float* cmine, int smax, float pad,
+                                                int j, int lane, bool rescale_pending, unsigned flags) {
+  using G = QuadGeom<M, D>;
+  int rank[R];
+  if constexpr (NB <= kQuadDppSlots) {
+    qd_ranks_first<R, D, NB>(q, rank);
+  } else {
+#pragma unroll
+    for (int s = 0; s < R; ++s) rank[s] = 0;
+    wave_lds_fence();
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+      if (kQuad * s + j < M) {
+        float* dst = cmine + (kQuad * s + j) * CW;
+#pragma unroll
+        for (int k = 0; k < D; ++k) dst[k] = q[s * D + k];
+      }
+    }
+    wave_lds_fence();
+    const int rows_end = kQuad * smax < M ? kQuad * smax : M;
+#pragma nounroll
+    for (int row = 0; row < rows_end; ++row) {
+      float pj[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) pj[k] = cmine[row * CW + k];
+      const bool lj = pj[0] < INFINITY;
+#pragma unroll
+      for (int s = 0; s < NB; ++s) rank[s] += (int)(lj & key_gt<D, kKeyFirst>(pj, &q[s * D]));
+    }
+    wave_lds_fence();
+  }
+  if (rescale_pending) qd_rescale<R, D, NB>(q, flags);
+  int gi = lane >> 2;
+  asm volatile("" : "+v"(gi));
+  float* mine = region + gi * G::N;
+  wave_lds_fence();
+#pragma unroll
+  for (int it = 0; it < G::QL; ++it) {
+    const int qq = lane + it * kWave;
+    if (qq < kQuadGames * G::Q) {
+      if constexpr (G::W == 4) *reinterpret_cast<vf4*>(region + qq * 4) = vf4{pad, pad, pad, pad};
+      else if constexpr (G::W == 2) *reinterpret_cast<vf2*>(region + qq * 2) = vf2{pad, pad};
+      else region[qq] = pad;
+    }
+  }
+  wave_lds_fence();
+  unrolled_while<0, NB>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (s >= smax) return false;
+    if (q[s * D] < INFINITY) {
+      float* dst = mine + rank[s] * D;
+#pragma unroll
+      for (int k = 0; k < D; ++k) dst[k] = q[s * D + k];
+    }
+    return true;
+  });
+  wave_lds_fence();
+}
+
 // ZEIL: Zeillinger's host (jax/players.py:55-109) on four lanes per game -- the quad parks its rows by rank (4 s + j)
 // in the compact image (scratch between the stages), lane j takes the rows i = j, j + 4, ... against every later row as
 // a rolled loop, two pairs per pass (hk_fast_rows.h: zeil_pair, one packed key (L, S, pair index)); the four bests
@@ -375,7 +440,8 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   __builtin_amdgcn_sched_barrier(0);
   const float pad = prm.pad_f32;
   const unsigned flags = (HOT == kHotJax) ? (unsigned)HK_SEM_JAX : (HOT == kHotTorch) ? kHotTorchFlags : prm.flags;
-  const unsigned stages = HOT ? (unsigned)(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON) : prm.stages;
+  const unsigned stages = (HOT == kHotJax || HOT == kHotTorch) ? (unsigned)(HK_STAGE_SHIFT | HK_STAGE_REPOSITION | HK_STAGE_NEWTON)
+                                                              : prm.stages;
   const float fill = ((flags & HK_SEM_MASK) == HK_SEM_JAX) ? -1.0f : pad;
   const int nsteps = prm.steps;
   uint32_t step0 = prm.step_offset;
@@ -642,6 +708,13 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   // (EPI: the last episode's final state; GEN: if anybody asks)
   const bool publish = !EPI || (last_episode && prm.out != nullptr);
   bool published = !publish;
+  // list semantics / COMPACT_SORTED (a run-time configured plain rollout of its own, kHotList -- the ranks cost the
+  // widest level registers the other configurations do not have to spare): sorted + compacted when published
+  constexpr bool kEndSort = HOT == kHotList;
+  static_assert(!kEndSort || (!REC && !ZEIL && !GEN && !EPI), "sorted output: plain rollouts");
+  const bool end_sort = kEndSort && nsteps > 0 && (stages & HK_STAGE_NEWTON) &&
+                        ((flags & HK_SEM_MASK) == HK_SEM_LIST || (flags & HK_FLAG_COMPACT_SORTED));
+  bool rescale_pending = false;
   PolicyCache zcache;  // (ZEIL: the lane's own Philox block, one per four steps)
   const uint64_t gg_game =  // (ZEIL) the policy stream's index of the game this lane plays
       ZEIL ? prm.game_offset + (has_ids ? (uint64_t)(uint32_t)__shfl((int)raw_id, gi) : (uint64_t)g) : 0;
@@ -704,7 +777,10 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
 #if defined(HK_QR_EXP) && HK_QR_EXP == 1
         if (!REC)
 #endif
-        np = qr_stages<M, CW, R, D, NB>(q, cmask, axis, np, j, flags, stages, cmine, smax);
+        // (end_sort: the last step's rescale waits until the rows are ranked, at the publish)
+        const unsigned st = (kEndSort && end_sort && t + 1 == nsteps) ? (stages & ~(unsigned)HK_STAGE_RESCALE) : stages;
+        if constexpr (kEndSort) rescale_pending = end_sort && t + 1 == nsteps && (stages & HK_STAGE_RESCALE);
+        np = qr_stages<M, CW, R, D, NB>(q, cmask, axis, np, j, flags, st, cmine, smax);
         if (!active) np = 2;
         const bool done = np < 2;
         if (done && length < 0) length = t + 1;
@@ -734,7 +810,8 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
       // staircase it would read every slot of every level: the whole row array stayed live through all the loops --
       // at (50,4), 52 + 13 registers under a 168-register budget: every lane spilled 212 - 332 B.) -------------------------
       if (!published && (t >= nsteps || stop)) {
-        qr_build_image<M, D, R, NB>(q, tags, region, smax, pad, j, lane);
+        if (kEndSort && end_sort) qr_build_sorted<M, CW, R, D, NB>(q, region, cmine, smax, pad, j, lane, rescale_pending, flags);
+        else qr_build_image<M, D, R, NB>(q, tags, region, smax, pad, j, lane);
         published = true;
       }
     });
@@ -774,15 +851,23 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
-// rollouts (no Zeillinger host, no sorted output) of float32, contiguous, W-aligned records
+inline bool quadroll_sorted_output(const Params& prm) {
+  return (prm.stages & HK_STAGE_NEWTON) &&
+         ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED));
+}
+
+// rollouts of float32, contiguous, W-aligned records
 inline bool quadroll_request_ok(const Params& prm) {
   if (prm.mode != kModeRollout || prm.m > 255) return false;
   // Zeillinger's host: plain rollouts (quadroll_kernel<..., ZEIL>)
   if (prm.host_policy == HK_HOST_ZEILLINGER &&
       (prm.obs_out || prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out))
     return false;
-  if ((prm.stages & HK_STAGE_NEWTON) &&
-      ((prm.flags & HK_SEM_MASK) == HK_SEM_LIST || (prm.flags & HK_FLAG_COMPACT_SORTED)))
+  // sorted + compacted output (list semantics): plain rollouts only -- ranked once, at the publish --, not under
+  // Zeillinger's host, whose tie-breaks follow the physical row order
+  if (quadroll_sorted_output(prm) &&
+      (prm.max_value > 0 || prm.episodes > 1 || prm.host_policy == HK_HOST_ZEILLINGER || prm.obs_out ||
+       prm.r_host_class_out || prm.r_axis_out || prm.r_done_out || prm.r_reward_out))
     return false;
   if (prm.flags & (HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_TEAM | HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES))
     return false;
@@ -816,6 +901,9 @@ int launch_quadroll_t(Params prm, hipStream_t stream) {
                        (const float*)prm.in, prm.in_stride, prm.batch, prm);
   else if (hot == kHotTorch)
     hipLaunchKernelGGL((quadroll_kernel<M, D, kHotTorch, WPB>), dim3(grid), dim3(kWave * WPB), 0, stream,
+                       (const float*)prm.in, prm.in_stride, prm.batch, prm);
+  else if (quadroll_sorted_output(prm))
+    hipLaunchKernelGGL((quadroll_kernel<M, D, kHotList, WPB>), dim3(grid), dim3(kWave * WPB), 0, stream,
                        (const float*)prm.in, prm.in_stride, prm.batch, prm);
   else
     hipLaunchKernelGGL((quadroll_kernel<M, D, kHotNone, WPB>), dim3(grid), dim3(kWave * WPB), 0, stream,

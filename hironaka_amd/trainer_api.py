@@ -264,6 +264,35 @@ class HipTrainer:
         tickets = [pipe.submit(x.contiguous()) for pipe, x in zip(self._gather_pipes, out)]
         return PendingRollout(self._gather_pipes, tickets)
 
+    # ---- jax_trainer.py:398-465 ----------------------------------------------------------------------------------
+    def validate(self, metric_fn: Optional[Callable] = None, verbose=0, batch_size=50, num_of_loops=10, max_length=None,
+                 write_wandb=False, key=None) -> Tuple[List, List]:
+        """The reference's battle schedule over `compute_rho`: the host network against the agent network and the three
+        fixed agents (random, choose_first, choose_last), then the three fixed hosts (random, all_coord, zeillinger)
+        against the agent network -- seven metrics (rho) and seven game-length histograms, in the reference's order.
+        The fixed strategies go BY NAME (fixed-vs-network pairs run the reference-shaped step loop over `hk_step`); the
+        networks as `action_wrapper(partial(policy_fns[role], params=...))`.  Logging / wandb stay with the caller
+        (control plane: out of scope)."""
+        from functools import partial
+        key = time.time_ns() % (1 << 62) if key is None else int(key)
+        metric_fn = self.compute_rho if metric_fn is None else metric_fn
+        host_net = action_wrapper(partial(self.policy_fns["host"], params=self.host_params), None)
+        agent_net = action_wrapper(partial(self.policy_fns["agent"], params=self.agent_params), None)
+        from . import players as _players
+        hosts = [host_net] + [get_host_with_flattened_obs(self.spec, getattr(_players, n))
+                              for n in ("random_host_fn", "all_coord_host_fn", "zeillinger_fn")]
+        agents = [agent_net] + [partial(getattr(_players, n), spec=self.spec)
+                                for n in ("random_agent_fn", "choose_first_agent_fn", "choose_last_agent_fn")]
+        schedule = [(0, i) for i in range(len(agents))] + [(i, 0) for i in range(1, len(hosts))]
+        rhos, details = [], []
+        for hi, ai in schedule:
+            key, _ = _split(key, 2)
+            rho, detail = metric_fn(hosts[hi], agents[ai], batch_size=batch_size, num_of_loops=num_of_loops,
+                                    max_length=max_length, write_wandb=False, key=key)
+            rhos.append(rho)
+            details.append(detail)
+        return rhos, details
+
     def rollout_postprocess(self, rollouts, role: str, use_unified_tree=True):
         """jax_trainer.py:558-592"""
         return _rollout_postprocess(rollouts, role, self.dimension, self.discount, use_unified_tree)

@@ -34,7 +34,7 @@ def test_round1_fuzz_mismatch_regression(sem, rstages):
     for seed, hp, ap in ((1, A.HK_HOST_RANDOM, A.HK_AGENT_RANDOM), (2, A.HK_HOST_RANDOM, A.HK_AGENT_RANDOM_LEGAL),
                          (3, A.HK_HOST_ALL_COORD, A.HK_AGENT_CHOOSE_LAST), (4, A.HK_HOST_ZEILLINGER, A.HK_AGENT_RANDOM)):
         wp, wrec = CO.rollout(p, 12, seed, host_policy=hp, agent_policy=ap, stages=rstages, flags=flags_o, record=True)
-        for force in (0, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC):
+        for force in (0, A.HK_FLAG_FORCE_ONE_LANE, A.HK_FLAG_FORCE_FOUR_LANES, A.HK_FLAG_FORCE_TEAM, A.HK_FLAG_FORCE_GENERIC):
             Q = P.clone()
             rec = ops.rollout(Q, 12, seed, host_policy=hp, agent_policy=ap, stages=rstages, flags=flags_p | force,
                               record=("obs", "host_class", "axis", "done", "reward", "game_length"))

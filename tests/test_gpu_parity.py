@@ -602,6 +602,40 @@ def test_reordered_batch_with_game_ids_rolls_out_like_the_original(spec):
 
 
 @pytest.mark.parametrize("spec", [(10, 3), (20, 3), (20, 4), (50, 4)])
+def test_sorted_plain_rollouts_on_four_lanes_match_oracle(spec):
+    """list semantics / COMPACT_SORTED on the four-lane rollout kernel (`quadroll_kernel<..., kHotList>`): the state is
+    ranked once, when it is published -- at whatever level of the staircase the episode ends (one step from dense
+    states: the widest level's rolled ranking; long episodes: the DPP ranking), before a pending rescale.  Against the
+    oracle and the other families, from generated, dense, fractional and partly finished states, with a ragged last
+    wave and one game off the exact path."""
+    m, d = spec
+    rng = np.random.default_rng(5 * m + d)
+    b = 16 * 9 + 5
+    starts = {"generated": CO.generate_points(b, m, d, 20, 4),
+              "dense": rng.integers(0, 30, (b, m, d)).astype(np.float32),
+              "fractional": (rng.integers(0, 9, (b, m, d)) / np.float32(9)).astype(np.float32)}
+    starts["holes"] = np.where(rng.random((b, m, 1)) < 0.5, np.float32(-1.0), starts["dense"]).astype(np.float32)
+    starts["irregular"] = starts["generated"].copy()
+    starts["irregular"][21, 1, 0] = -1.0
+    for name, p0 in starts.items():
+        for sem, compact in (("list", False), ("jax", True), ("torch", True)):
+            fo = CO.flags_of(sem=sem, noop_if_invalid=sem != "jax", ignore_ended=sem == "torch", compact_sorted=compact)
+            fp = ops.make_flags(sem, sem != "jax", sem == "torch", compact_sorted=compact)
+            for stages in (7, 15):
+                for T in (0, 1, 2, 7, 30):
+                    for hp, ap in ((A.HK_HOST_RANDOM, A.HK_AGENT_RANDOM_LEGAL), (A.HK_HOST_ALL_COORD, A.HK_AGENT_CHOOSE_LAST)):
+                        want_p, want = CO.rollout(p0, T, 3, game_offset=9, host_policy=hp, agent_policy=ap, stages=stages,
+                                                  flags=fo, record=False)
+                        for fam in (0, A.HK_FLAG_FORCE_FOUR_LANES):
+                            Q = dev(p0.copy())
+                            got = ops.rollout(Q, T, 3, game_offset=9, host_policy=hp, agent_policy=ap, stages=stages,
+                                              flags=fp | fam, record=("game_length",))
+                            assert np.array_equal(host(Q), want_p), (name, sem, compact, stages, T, hp, fam)
+                            assert np.array_equal(host(got["game_length"]), want["game_length"])
+                            assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"])
+
+
+@pytest.mark.parametrize("spec", [(10, 3), (20, 3), (20, 4), (50, 4)])
 def test_binning_on_the_device_matches_oracle(spec):
     """hk_bin_by_live_rows / hk_generate_points_binned (ABI 4): the order local to groups of games (widest first, equal
     games in their order, the k-th sixteen games of all full groups together, a partial last group in place) equals

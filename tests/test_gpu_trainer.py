@@ -111,6 +111,19 @@ def test_captured_searches_are_replayed_not_recaptured(monkeypatch):
                for x, y in zip(first, again))
 
 
+def test_validate_runs_the_reference_schedule():
+    """HipTrainer.validate (jax_trainer.py:398-465): seven pairings in the reference's order -- the host network against
+    the agent network and the three fixed agents, then the three fixed hosts against the agent network --, each a rho in
+    [0, 1] with a histogram of max_length bins; deterministic in the key"""
+    t = make_trainer()
+    rhos, details = t.validate(batch_size=64, num_of_loops=2, max_length=8, key=5)
+    assert len(rhos) == 7 and len(details) == 7
+    assert all(len(dt) == 8 and sum(dt) <= 128 for dt in details)
+    assert all((r != r) or 0.0 <= r <= 1.0 for r in rhos)
+    again = t.validate(batch_size=64, num_of_loops=2, max_length=8, key=5)
+    assert again[1] == details
+
+
 def test_simulate_baseline_config5_at_size():
     """BASELINE configs[4]: batch 8192, 32 simulations per move, 20 moves, dim 3, 20 points, one hipGraph per
     search.  Checked: shapes, rollout_sanity_tests, value range, and that consecutive observations of every game are
