@@ -430,7 +430,7 @@ __device__ __forceinline__ int duo_zeillinger(const float (&q)[CH * D], int h, f
     for (int a = 0; a < NB; ++a) {
 #pragma unroll
       for (int b = a + 1; b < NB; ++b)
-        zeil_pair<D, true>(best, &q[a * D], &q[b * D], true, (128 * a + 2 * b) + 65 * h);
+        zeil_pair<D, true, false>(best, &q[a * D], &q[b * D], true, (128 * a + 2 * b) + 65 * h);
 #pragma unroll
       for (int b = a; b < NB; ++b)
         zeil_pair<D, true>(best, &q[a * D], &p[b * D], (b > a) | (h == 0), (128 * a + 2 * b + 1) + 63 * h);
@@ -461,8 +461,8 @@ __device__ __forceinline__ int duo_zeillinger(const float (&q)[CH * D], int h, f
           pj[k] = mine[j * D + k];
           pk[k] = mine[j2 * D + k];
         }
-        zeil_pair<D, false>(best, pi, pj, true, 64 * i + j);
-        zeil_pair<D, false>(second, pi, pk, j + 1 < n, 64 * i + j + 1);
+        zeil_pair<D, false, false>(best, pi, pj, true, 64 * i + j);
+        zeil_pair<D, false, false>(second, pi, pk, true, 64 * i + j + 1);  // (past the end: the last pair again, later)
       }
     }
     zeil_merge<D, false>(best, second);
@@ -477,7 +477,7 @@ __device__ __forceinline__ int duo_zeillinger(const float (&q)[CH * D], int h, f
     }
     zeil_merge<D, KEEP>(best, o);
   }
-  const bool have = best.hi != 0xFFFFFFFFu;
+  const bool have = best.have();
   if constexpr (!KEEP) {  // the chosen pair's difference from the parked rows
     const int i = have ? (int)((best.lo & 0xFFFFu) >> 6) : 0, j = have ? (int)(best.lo & 63u) : 0;
 #pragma unroll

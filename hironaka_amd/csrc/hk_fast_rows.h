@@ -538,19 +538,55 @@ __device__ __forceinline__ int c_zeillinger(const float (&q)[C * D], int nmax, b
   return encode_mask((1u << lo) | (1u << hi));
 }
 
+// ---- multi-word unsigned compares as borrow chains (v_subb_co, the borrow travelling in a scalar register pair), their
+// results added to counters (v_addc_co) or selecting (v_cndmask) without a detour through scalar and/or logic ----------
+using LaneMask = uint64_t;
+__device__ __forceinline__ LaneMask kb_subb(uint32_t mine, uint32_t other, LaneMask borrow_in) {
+  uint32_t diff;
+  LaneMask borrow;
+  asm("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(diff), "=s"(borrow) : "v"(mine), "v"(other), "s"(borrow_in));
+  return borrow;
+}
+__device__ __forceinline__ void kb_count(uint32_t& n, LaneMask c) {
+  LaneMask carry;
+  asm("v_addc_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(n), "=s"(carry) : "s"(c));
+}
+// lanes where `other` comes first: other > mine, or other == mine on the lanes of `tie` (words: least significant first)
+template <int W>
+__device__ __forceinline__ LaneMask key_other_first(const uint32_t (&mine)[W], const uint32_t (&other)[W], LaneMask tie) {
+  LaneMask c = kb_subb(mine[0], other[0], tie);
+#pragma unroll
+  for (int i = 1; i < W; ++i) c = kb_subb(mine[i], other[i], c);
+  return c;
+}
+__device__ __forceinline__ uint32_t kb_select(uint32_t keep, uint32_t take, LaneMask c) {
+  uint32_t r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(keep), "v"(take), "s"(c));
+  return r;
+}
+__device__ __forceinline__ float kb_select(float keep, float take, LaneMask c) {
+  return __uint_as_float(kb_select(__float_as_uint(keep), __float_as_uint(take), c));
+}
+
 // ---- Zeillinger's pair test for the kernels that split a game over lanes (hk_duo_kernel.h, hk_quadroll_kernel.h) ------
 // The best pair so far as ONE comparable key: hi = the bits of L (a non-negative finite float: its bit pattern orders
 // like its value), lo = S << 16 | 64 i + j -- "smaller (L, S), then the earlier pair" is an unsigned compare of (hi, lo).
 template <int D>
 struct ZeilBest {
-  uint32_t hi = 0xFFFFFFFFu, lo = 0xFFFFFFFFu;  // (all ones: none yet)
-  float bd[D];                                  // the pair's difference (KEEP; else re-read from the parked rows)
+  // none yet: just above the pattern of +inf -- below every NaN, which is what L comes out as when either row is a hole
+  // (every difference +-inf or NaN): holes need no test of their own
+  static constexpr uint32_t kNone = 0x7F800001u;
+  uint32_t hi = kNone, lo = 0xFFFFFFFFu;
+  float bd[D];  // the pair's difference (KEEP; else re-read from the parked rows)
+  __device__ __forceinline__ bool have() const { return hi < kNone; }
 };
 
-// one pair (mine = the earlier row i, other = row j): its characteristic vector against the best so far.  ~25
-// instructions: max / min / median of three are single instructions, #max + #min = 2 + (median == max) + (median == min)
-// in dimension 3; every term is bitwise (with && / || the compiler made each one a branch on the exec mask: 14 per pair)
-template <int D, bool KEEP>
+// one pair (mine = the earlier row i, other = row j): its characteristic vector against the best so far.  max / min /
+// median of three are single instructions, #max + #min = 2 + (median == max) + (median == min) in dimension 3; in
+// dimension 4 two rounds of a sorting network leave minimum, maximum and the two middle values, #max + #min = 2 + the
+// middle values' matches.  "better" is the borrow of key - best over the two words, selecting directly.
+// OK = false: the caller has no pairs to leave out (`ok` is not looked at).
+template <int D, bool KEEP, bool OK = true>
 __device__ __forceinline__ void zeil_pair(ZeilBest<D>& best, const float* mine, const float* other, bool ok, int idx) {
   float v[D];
 #pragma unroll
@@ -562,6 +598,14 @@ __device__ __forceinline__ void zeil_pair(ZeilBest<D>& best, const float* mine, 
     mn = __builtin_fminf(__builtin_fminf(v[0], v[1]), v[2]);
     const float md = __builtin_amdgcn_fmed3f(v[0], v[1], v[2]);
     cnt = 2u + (uint32_t)(md == mx) + (uint32_t)(md == mn);
+  } else if constexpr (D == 4) {
+    const float lo1 = __builtin_fminf(v[0], v[1]), hi1 = __builtin_fmaxf(v[0], v[1]);
+    const float lo2 = __builtin_fminf(v[2], v[3]), hi2 = __builtin_fmaxf(v[2], v[3]);
+    mn = __builtin_fminf(lo1, lo2);
+    mx = __builtin_fmaxf(hi1, hi2);
+    const float m1 = __builtin_fmaxf(lo1, lo2), m2 = __builtin_fminf(hi1, hi2);
+    // (all four equal would count 6, not 8: that pair is `close` and does not count at all)
+    cnt = 2u + (uint32_t)(m1 == mn) + (uint32_t)(m2 == mn) + (uint32_t)(m1 == mx) + (uint32_t)(m2 == mx);
   } else {
     mx = v[0];
     mn = v[0];
@@ -576,25 +620,25 @@ __device__ __forceinline__ void zeil_pair(ZeilBest<D>& best, const float* mine, 
   }
   const float L = mx - mn;
   const bool close = fabsf(L) <= 1e-8f + 1e-5f * fabsf(mn);  // jnp.isclose(max, min)
-  const bool valid = ok & (mine[0] < INFINITY) & (other[0] < INFINITY) & !close;
-  const uint32_t khi = __float_as_uint(L), klo = (cnt << 16) | (uint32_t)idx;
-  const bool better = valid & ((khi < best.hi) | ((khi == best.hi) & (klo < best.lo)));
-  best.hi = better ? khi : best.hi;
-  best.lo = better ? klo : best.lo;
+  const bool out = OK ? (close | !ok) : close;
+  const uint32_t khi = out ? 0xFFFFFFFFu : __float_as_uint(L), klo = (cnt << 16) | (uint32_t)idx;
+  const LaneMask better = kb_subb(khi, best.hi, kb_subb(klo, best.lo, 0ull));  // best > key
+  best.hi = kb_select(best.hi, khi, better);
+  best.lo = kb_select(best.lo, klo, better);
   if constexpr (KEEP) {
 #pragma unroll
-    for (int k = 0; k < D; ++k) best.bd[k] = better ? v[k] : best.bd[k];
+    for (int k = 0; k < D; ++k) best.bd[k] = kb_select(best.bd[k], v[k], better);
   }
 }
 
 template <int D, bool KEEP>
 __device__ __forceinline__ void zeil_merge(ZeilBest<D>& best, const ZeilBest<D>& o) {
-  const bool take = (o.hi < best.hi) | ((o.hi == best.hi) & (o.lo < best.lo));
-  best.hi = take ? o.hi : best.hi;
-  best.lo = take ? o.lo : best.lo;
+  const LaneMask take = kb_subb(o.hi, best.hi, kb_subb(o.lo, best.lo, 0ull));
+  best.hi = kb_select(best.hi, o.hi, take);
+  best.lo = kb_select(best.lo, o.lo, take);
   if constexpr (KEEP) {
 #pragma unroll
-    for (int k = 0; k < D; ++k) best.bd[k] = take ? o.bd[k] : best.bd[k];
+    for (int k = 0; k < D; ++k) best.bd[k] = kb_select(best.bd[k], o.bd[k], take);
   }
 }
 

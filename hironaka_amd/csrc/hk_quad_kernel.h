@@ -533,35 +533,6 @@ __device__ __forceinline__ void qd_newton_two_level(float (&q)[R * D], float* cm
   wave_lds_fence();  // the compact image is written again after the stages
 }
 
-// list semantics (_list_ops.py:25-41): position of each of the lane's rows among the game's live rows in descending
-// lexicographic order, coordinate 0 first (rows are distinct after the Newton stage): the rows of the other three
-// lanes arrive through DPP, every lane counts for its own rows
-template <int R, int D, int NB>
-__device__ __forceinline__ void qd_ranks_first(const float (&q)[R * D], int (&rank)[R]) {
-#pragma unroll
-  for (int s = 0; s < R; ++s) rank[s] = 0;
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    float p1[D], p2[D], p3[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-      p1[k] = qperm<kQuadUp1>(q[b * D + k]);
-      p2[k] = qperm<kQuadUp2>(q[b * D + k]);
-      p3[k] = qperm<kQuadUp3>(q[b * D + k]);
-    }
-    const bool l0 = q[b * D] < INFINITY, l1 = p1[0] < INFINITY, l2 = p2[0] < INFINITY, l3 = p3[0] < INFINITY;
-#pragma unroll
-    for (int a = 0; a < NB; ++a) {
-      // (every comparison unconditionally, `&` not `&&`: as short circuits they became exec-masked branches whose
-      // counters lived in scratch)
-      if (a != b) rank[a] += (int)(l0 & key_gt<D, kKeyFirst>(&q[b * D], &q[a * D]));
-      rank[a] += (int)(l1 & key_gt<D, kKeyFirst>(p1, &q[a * D]));
-      rank[a] += (int)(l2 & key_gt<D, kKeyFirst>(p2, &q[a * D]));
-      rank[a] += (int)(l3 & key_gt<D, kKeyFirst>(p3, &q[a * D]));
-    }
-  }
-}
-
 // observation features (jax/util.py:186-197, last coordinate primary; `coord0`: core/tensor_points.py:72-74, coordinate
 // 0 alone): position of each of the lane's rows in descending key order, rows with EQUAL keys in row order (their
 // compact rank: 4 s + lane).  Every pair of the game once -- own slots' triangle, ALL pairs with the lane one up, the
@@ -582,100 +553,159 @@ __device__ __forceinline__ void qd_key_cmp(const float* a, const float* b, bool 
   }
 }
 
-template <int R, int D, int NB>
-__device__ __forceinline__ void qd_ranks_stable(const float (&q)[R * D], int j, bool coord0, int (&rank)[R]) {
-  int o1[NB], o2[NB];  // rows of mine that come before the partner's slot b
+// ---- key comparisons as borrow chains.  On the exact path every coordinate of a live row lies in [+0, +inf) by its bit
+// pattern (the guard), so float order is the order of the patterns as unsigned integers and a key of W coordinates is
+// ONE W-word number: `other > mine` is the borrow out of mine - other (v_sub_co / v_subb_co, W instructions, the borrow
+// travelling in a scalar register pair), and `other > mine, or equal and tie` the same chain with `tie` as its borrow in.
+// The borrow is added to a counter as it is (v_addc_co).  Before: W greater-than + W equal compares whose results met
+// in scalar and/or chains -- ~14 vector + ~10 scalar instructions per pair, now W + 2 and none.
+// Liveness rides in the key: the most significant word is pattern + 1 for a live row and 0 for a hole, so a hole is
+// below every live row and never counted as coming first.  (kb_subb / kb_count / key_other_first: hk_fast_rows.h)
+// the key words of slot s (least significant first).  KEY: kKeyLast (observation features, jax/util.py:186-197: last
+// coordinate primary), kKeyFirst (list semantics, coordinate 0 primary), kKeyCoord0 (core/tensor_points.py:72-74:
+// coordinate 0 alone)
+template <int D, int KEY>
+constexpr int key_words() { return KEY == kKeyCoord0 ? 1 : D; }
+template <int D, int KEY>
+__device__ __forceinline__ void key_of(const float* row, uint32_t (&w)[key_words<D, KEY>()]) {
+  constexpr int W = key_words<D, KEY>();
+  const bool live = row[0] < INFINITY;
+  const int top = (KEY == kKeyLast) ? D - 1 : 0;
 #pragma unroll
-  for (int s = 0; s < R; ++s) rank[s] = 0;
+  for (int i = 0; i + 1 < W; ++i) w[i] = __float_as_uint(row[KEY == kKeyLast ? i : D - 1 - i]);
+  w[W - 1] = live ? __float_as_uint(row[top]) + 1u : 0u;
+}
+
+// Every pair of the game once -- own slots' triangle, ALL pairs with the lane one up, the pairs a <= b with the lane two
+// up, as in qd_newton -- and what a lane counts for a partner's rows travels back.  A partner's slot b receives `the
+// number of my LIVE rows that come before it`: my holes lose against every live row, so that is (pairs counted) -
+// (pairs the partner's row won) without a look at my liveness.
+template <int R, int D, int NB, int KEY>
+__device__ __forceinline__ void qd_ranks_stable_t(const float (&q)[R * D], int j, int (&rank)[R]) {
+  constexpr int W = key_words<D, KEY>();
+  uint32_t kw[NB][W];
+  uint32_t rk[NB], won1[NB], won2[NB], diag2[NB];  // won: pairs the partner's slot b won against my rows
 #pragma unroll
-  for (int s = 0; s < NB; ++s) o1[s] = o2[s] = 0;
-  bool live[NB];
+  for (int s = 0; s < NB; ++s) {
+    key_of<D, KEY>(&q[s * D], kw[s]);
+    rk[s] = won1[s] = won2[s] = diag2[s] = 0u;
+  }
+  const LaneMask none = 0ull;
+  const LaneMask all = ~0ull, late1 = 0x8888888888888888ull, early2 = 0x3333333333333333ull;  // lane 3 of a quad; lanes 0, 1
+  uint32_t ownlost[NB];
 #pragma unroll
-  for (int s = 0; s < NB; ++s) live[s] = q[s * D] < INFINITY;
+  for (int s = 0; s < NB; ++s) ownlost[s] = 0u;
 #pragma unroll
   for (int a = 0; a + 1 < NB; ++a)
 #pragma unroll
-    for (int b = a + 1; b < NB; ++b) {  // own slots: a is the earlier row
-      bool gt, eq;
-      qd_key_cmp<D>(&q[b * D], &q[a * D], coord0, gt, eq);  // b first iff its key is strictly greater
-      rank[a] += (gt && live[b]) ? 1 : 0;
-      rank[b] += (!gt && live[a]) ? 1 : 0;
+    for (int b = a + 1; b < NB; ++b) {  // own slots: a is the earlier row, b first iff its key is strictly greater
+      const LaneMask c = key_other_first<W>(kw[a], kw[b], none);
+      kb_count(rk[a], c);
+      kb_count(ownlost[b], c);
     }
-  const bool late1 = j == 3, late2 = j >= 2;  // on the diagonal the partner's row is the earlier one
+#pragma unroll
+  for (int b = 1; b < NB; ++b) rk[b] += (uint32_t)b - ownlost[b];  // (my holes a < b lose against a live b)
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    float p1[D], p2[D];
+    uint32_t p1[W], p2[W];
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
-      p1[k] = qperm<kQuadUp1>(q[b * D + k]);
-      p2[k] = qperm<kQuadUp2>(q[b * D + k]);
+    for (int i = 0; i < W; ++i) {
+      p1[i] = (uint32_t)qperm_i<kQuadUp1>((int)kw[b][i]);
+      p2[i] = (uint32_t)qperm_i<kQuadUp2>((int)kw[b][i]);
     }
-    const bool l1 = p1[0] < INFINITY, l2 = p2[0] < INFINITY;
 #pragma unroll
     for (int a = 0; a < NB; ++a) {
-      {  // the lane one up: all pairs; its row is the earlier one iff b < a, or b == a on lane 3
-        bool gt, eq;
-        qd_key_cmp<D>(p1, &q[a * D], coord0, gt, eq);
-        const bool other_first = gt || (eq && (b < a || (b == a && late1)));
-        rank[a] += (other_first && l1) ? 1 : 0;
-        o1[b] += (!other_first && live[a]) ? 1 : 0;
+      {  // the lane one up: all pairs; on equal keys its row is the earlier one iff b < a, or b == a on lane 3
+        const LaneMask c = key_other_first<W>(kw[a], p1, b < a ? all : (b == a ? late1 : none));
+        kb_count(rk[a], c);
+        kb_count(won1[b], c);
       }
-      if (a <= b) {  // the lane two up: pairs a < b (it does the mirror image); the diagonal is counted ONCE, by the
-        bool gt, eq;   // lower lane of the two (counts add up, unlike the verdicts of the domination test)
-        qd_key_cmp<D>(p2, &q[a * D], coord0, gt, eq);
-        const bool mine_counts = a < b || !late2;
-        const bool other_first = gt;  // (equal keys: my row is the earlier one wherever this pair is counted)
-        rank[a] += (mine_counts && other_first && l2) ? 1 : 0;
-        o2[b] += (mine_counts && !other_first && live[a]) ? 1 : 0;
+      if (a < b) {  // the lane two up: pairs a < b (it does the mirror image); equal keys: my row is the earlier one
+        const LaneMask c = key_other_first<W>(kw[a], p2, none);
+        kb_count(rk[a], c);
+        kb_count(won2[b], c);
+      } else if (a == b) {  // the diagonal is counted ONCE, by the lower lane of the two
+        const LaneMask c = key_other_first<W>(kw[a], p2, none);
+        LaneMask live_a;
+        asm("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(live_a) : "v"(kw[a][W - 1]));
+        kb_count(rk[a], c & early2);
+        kb_count(diag2[b], ~c & early2 & live_a);
       }
     }
   }
 #pragma unroll
-  for (int s = 0; s < NB; ++s)  // what the lane one DOWN and the lane two up counted for my slot s
-    rank[s] += qperm_i<kQuadUp3>(o1[s]) + qperm_i<kQuadUp2>(o2[s]);
+  for (int s = 0; s < R; ++s) rank[s] = 0;
+#pragma unroll
+  for (int s = 0; s < NB; ++s) {  // what the lane one DOWN and the lane two up counted for my slot s
+    const uint32_t o1 = (uint32_t)NB - won1[s], o2 = (uint32_t)s - won2[s] + diag2[s];
+    rank[s] = (int)(rk[s] + (uint32_t)qperm_i<kQuadUp3>((int)o1) + (uint32_t)qperm_i<kQuadUp2>((int)o2));
+  }
+}
+// list semantics (_list_ops.py:25-41): descending lexicographic order, coordinate 0 first.  Rows are distinct after the
+// Newton stage, so the tie rules above never apply and the same pair-once walk serves.
+template <int R, int D, int NB>
+__device__ __forceinline__ void qd_ranks_first(const float (&q)[R * D], int (&rank)[R]) {
+  qd_ranks_stable_t<R, D, NB, kKeyFirst>(q, 0, rank);
+}
+template <int R, int D, int NB>
+__device__ __forceinline__ void qd_ranks_stable(const float (&q)[R * D], int j, bool coord0, int (&rank)[R]) {
+  if (coord0) qd_ranks_stable_t<R, D, NB, kKeyCoord0>(q, j, rank);
+  else qd_ranks_stable_t<R, D, NB, kKeyLast>(q, j, rank);
 }
 
 // The same ranks for MANY slots per lane (more than kQuadDppSlots: states no Newton pass has thinned, (50,4) only): the
-// quad parks its rows at their compact ranks (4 s + lane) and every lane walks ALL the game's rows -- one broadcast read
-// per row -- against its own slots: a row comes first iff its key is greater, or equal with the lower compact rank.
-template <int M, int CW, int R, int D, int NB>
-__device__ __forceinline__ void qd_ranks_lds(const float (&q)[R * D], float* cmine, int j, int rows_end, bool coord0,
-                                             int (&rank)[R]) {
-#pragma unroll
-  for (int s = 0; s < R; ++s) rank[s] = 0;
+// quad parks the KEYS of its rows at their compact ranks (4 s + lane) and every lane walks ALL the game's rows -- one
+// broadcast read per row -- against its own slots: a row comes first iff its key is greater, or (TIES) equal with the
+// lower compact rank -- that condition, a compare of the loop counter, is the chain's borrow in.
+template <int M, int CW, int R, int D, int NB, int KEY, bool TIES>
+__device__ __forceinline__ void qd_ranks_lds_t(const float (&q)[R * D], float* cmine, int j, int rows_end, int (&rank)[R]) {
+  constexpr int W = key_words<D, KEY>();
+  static_assert(CW >= W, "a parked key fits a parked row");
+  uint32_t kw[NB][W], rk[NB];
 #pragma unroll
   for (int s = 0; s < NB; ++s) {
+    key_of<D, KEY>(&q[s * D], kw[s]);
+    rk[s] = 0u;
     if (kQuad * s + j < M) {
-      float* dst = cmine + (kQuad * s + j) * CW;
-      if constexpr (D == 4) {
-        *reinterpret_cast<vf4*>(dst) = vf4{q[s * D], q[s * D + 1], q[s * D + 2], q[s * D + 3]};
+      uint32_t* dst = reinterpret_cast<uint32_t*>(cmine) + (kQuad * s + j) * CW;
+      if constexpr (W == 4) {
+        *reinterpret_cast<uint4*>(dst) = uint4{kw[s][0], kw[s][1], kw[s][2], kw[s][3]};
       } else {
 #pragma unroll
-        for (int k = 0; k < D; ++k) dst[k] = q[s * D + k];
+        for (int i = 0; i < W; ++i) dst[i] = kw[s][i];
       }
     }
   }
   wave_lds_fence();
 #pragma nounroll
   for (int row = 0; row < rows_end; ++row) {
-    float pj[D];
-    if constexpr (D == 4) {
-      const vf4 v = *reinterpret_cast<const vf4*>(cmine + row * CW);
+    uint32_t pj[W];
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(cmine) + row * CW;
+    if constexpr (W == 4) {
+      const uint4 v = *reinterpret_cast<const uint4*>(src);
       pj[0] = v.x; pj[1] = v.y; pj[2] = v.z; pj[3] = v.w;
     } else {
 #pragma unroll
-      for (int k = 0; k < D; ++k) pj[k] = cmine[row * CW + k];
+      for (int i = 0; i < W; ++i) pj[i] = src[i];
     }
-    const bool lj = pj[0] < INFINITY;
     const int dj = row - j;  // (row < 4 s + j  <=>  dj < 4 s)
 #pragma unroll
     for (int s = 0; s < NB; ++s) {
-      bool gt, eq;
-      qd_key_cmp<D>(pj, &q[s * D], coord0, gt, eq);
-      rank[s] += (lj & (gt | (eq & (dj < kQuad * s)))) ? 1 : 0;
+      const LaneMask tie = TIES ? __ballot(dj < kQuad * s) : 0ull;
+      kb_count(rk[s], key_other_first<W>(kw[s], pj, tie));
     }
   }
+#pragma unroll
+  for (int s = 0; s < R; ++s) rank[s] = 0;
+#pragma unroll
+  for (int s = 0; s < NB; ++s) rank[s] = (int)rk[s];
   wave_lds_fence();  // (the compact image is written again afterwards)
+}
+template <int M, int CW, int R, int D, int NB>
+__device__ __forceinline__ void qd_ranks_lds(const float (&q)[R * D], float* cmine, int j, int rows_end, bool coord0,
+                                             int (&rank)[R]) {
+  if (coord0) qd_ranks_lds_t<M, CW, R, D, NB, kKeyCoord0, true>(q, cmine, j, rows_end, rank);
+  else qd_ranks_lds_t<M, CW, R, D, NB, kKeyLast, true>(q, cmine, j, rows_end, rank);
 }
 
 // one transition on slots [0, NB) of the four lanes; returns the GAME's number of live rows.  `sorted` (list
@@ -1478,9 +1508,6 @@ bool quad_ok_t(const Params& prm) {
 inline bool quad_supported(const Params& prm, int dtype) {
   if (dtype != HK_F32 || prm.mode != kModeStep) return false;
   if (prm.class_out) return false;
-  // (the large games: the torch container's one-coordinate sort stays with the team kernel -- 117 us at (50,4) x 262 144
-  // against 144 us here; the observation features are ahead here: 150 against 179 us)
-  if ((prm.stages & kStageFeatureSort0) && prm.m * prm.d > 128) return false;
   if (prm.coords_kind == HK_COORDS_IN_RECORD) return false;
   if (prm.flags & (HK_FLAG_FORCE_GENERIC | HK_FLAG_FORCE_TEAM | HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES))
     return false;

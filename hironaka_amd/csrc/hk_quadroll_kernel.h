@@ -268,29 +268,8 @@ __device__ __forceinline__ void qr_build_sorted(float (&q)[R * D], float* region
   if constexpr (NB <= kQuadDppSlots) {
     qd_ranks_first<R, D, NB>(q, rank);
   } else {
-#pragma unroll
-    for (int s = 0; s < R; ++s) rank[s] = 0;
     wave_lds_fence();
-#pragma unroll
-    for (int s = 0; s < NB; ++s) {
-      if (kQuad * s + j < M) {
-        float* dst = cmine + (kQuad * s + j) * CW;
-#pragma unroll
-        for (int k = 0; k < D; ++k) dst[k] = q[s * D + k];
-      }
-    }
-    wave_lds_fence();
-    const int rows_end = kQuad * smax < M ? kQuad * smax : M;
-#pragma nounroll
-    for (int row = 0; row < rows_end; ++row) {
-      float pj[D];
-#pragma unroll
-      for (int k = 0; k < D; ++k) pj[k] = cmine[row * CW + k];
-      const bool lj = pj[0] < INFINITY;
-#pragma unroll
-      for (int s = 0; s < NB; ++s) rank[s] += (int)(lj & key_gt<D, kKeyFirst>(pj, &q[s * D]));
-    }
-    wave_lds_fence();
+    qd_ranks_lds_t<M, CW, R, D, NB, kKeyFirst, false>(q, cmine, j, kQuad * smax < M ? kQuad * smax : M, rank);
   }
   if (rescale_pending) qd_rescale<R, D, NB>(q, flags);
   int gi = lane >> 2;
@@ -359,8 +338,8 @@ __device__ __forceinline__ int qr_zeillinger(const float (&q)[R * D], float* cmi
         pj[k] = cmine[jj * CW + k];
         pk[k] = cmine[j2 * CW + k];
       }
-      zeil_pair<D, false>(best, pi, pj, true, 64 * i + jj);
-      zeil_pair<D, false>(second, pi, pk, jj + 1 < n, 64 * i + jj + 1);
+      zeil_pair<D, false, false>(best, pi, pj, true, 64 * i + jj);
+      zeil_pair<D, false, false>(second, pi, pk, true, 64 * i + jj + 1);  // (past the end: the last pair again, later)
     }
   }
   zeil_merge<D, false>(best, second);
@@ -373,7 +352,7 @@ __device__ __forceinline__ int qr_zeillinger(const float (&q)[R * D], float* cmi
     o.lo = (uint32_t)qperm_i<kQuadUp2>((int)best.lo);
     zeil_merge<D, false>(best, o);
   }
-  const bool have = best.hi != 0xFFFFFFFFu;
+  const bool have = best.have();
   const int bi = have ? (int)((best.lo & 0xFFFFu) >> 6) : 0, bj = have ? (int)(best.lo & 63u) : 0;
   float bd[D];
 #pragma unroll
