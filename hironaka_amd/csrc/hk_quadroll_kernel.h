@@ -305,7 +305,7 @@ __device__ __forceinline__ void qr_build_sorted(float (&q)[R * D], float* region
 // merge through two DPP rotations; the chosen pair's difference is re-read from the parked rows.  hk_duo_kernel.h has
 // the two-lane twin.
 template <int M, int CW, int R, int D>
-__device__ __forceinline__ int qr_zeillinger(const float (&q)[R * D], float* cmine, int j, int smax) {
+__device__ __forceinline__ int qr_zeillinger(const float (&q)[R * D], float* cmine, int j, int smax, int np) {
   wave_lds_fence();
   unrolled_while<0, R>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
@@ -322,7 +322,13 @@ __device__ __forceinline__ int qr_zeillinger(const float (&q)[R * D], float* cmi
     return true;
   });
   wave_lds_fence();
-  const int n = (kQuad * smax < M) ? kQuad * smax : M;  // ranks in use (wave-uniform); holes are +inf
+  // ranks in use (wave-uniform; holes are +inf): the bucket's 4 smax, or -- `np`: a bound on the ranks in use of the
+  // lane's game, where the caller has one (freshly dealt rows: the live rows ARE the first np ranks; between two deals
+  // the survivors keep their slots and the caller passes M) -- the wave's largest game, at most three ballots below
+  // (the pair loop is quadratic in it)
+  int n = (kQuad * smax < M) ? kQuad * smax : M;
+#pragma nounroll
+  for (int t = 0; t < kQuad - 1 && n > 2 && !__any(np >= n); ++t) --n;
   ZeilBest<D> best, second;
 #pragma nounroll
   for (int i = j; i + 1 < n; i += kQuad) {
@@ -635,7 +641,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
     if (prm.class_out) {
       // hk_zeillinger (jax/players.py:55-109) as its own operator: Zeillinger's class of every game of the batch, the
       // launch's only product -- the rollout kernel's prologue (slab in, live rows to their slots) and its pair loop
-      const int zc = qr_zeillinger<M, CW, R, D>(q, cmine, j, smax);
+      const int zc = qr_zeillinger<M, CW, R, D>(q, cmine, j, smax, np);
       if (leader) (prm.class_out + g0)[(unsigned)gi] = zc;
       return;
     }
@@ -732,7 +738,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
         int axis;
         if constexpr (ZEIL) {
           // (a game with fewer than two rows has no pair: class 0 -- a wave of finished games skips the test)
-          const int zc = __any(active && np >= 2) ? qr_zeillinger<M, CW, R, D>(q, cmine, j, smax) : 0;
+          const int zc = __any(active && np >= 2) ? qr_zeillinger<M, CW, R, D>(q, cmine, j, smax, M) : 0;
           uint32_t ra, rb;
           int cls;
           policy_words(gg_game, step0 + (uint32_t)t, seed, zcache, D, ra, rb);
