@@ -688,6 +688,12 @@ def main():
         feat3 = us3(lambda i: ops.get_features(fresh3, out=out3.reshape(b3, m3 * d3)))
         featt3 = us3(lambda i: ops.get_features_torch(fresh3))
         zeil3 = us3(lambda i: ops.zeillinger(fresh3))
+        # list semantics (_list_ops.py:9-45: the state leaves the rollout sorted + compacted) and Zeillinger's host
+        list_flags = ops.make_flags("list", noop_if_invalid=True)
+        list3 = us3(lambda i: ops.rollout(state3, EPISODE, SEED, done_count=dc3, initial=fresh3, stages=stages,
+                                          flags=list_flags, agent_policy=A.HK_AGENT_RANDOM_LEGAL), reps=1)
+        zroll3 = us3(lambda i: ops.rollout(state3, EPISODE, SEED, done_count=dc3, initial=fresh3, stages=stages,
+                                           host_policy=A.HK_HOST_ZEILLINGER), reps=1)
         config3 = {"workload": f"dim={d3}, max_points={m3}, batch={b3} (BASELINE configs[2])",
                    "hk_step_us": s3 / 5 * 1e6, "hk_step_env_steps_per_s": b3 * 5 / s3,
                    "roofline": hbm_roofline(s3 / 5, b3 * bs3, kernel="hk_step at (50,4) x 262144 from generate_pts states"),
@@ -702,6 +708,8 @@ def main():
                    "generate_binned_us_per_batch": genb3, "binning_us_per_batch": bin3,
                    "compute_rho_us_per_loop": rho3, "compute_rho_us_per_loop_generate_then_rollout": rho3_two,
                    "get_features_us": feat3, "get_features_torch_us": featt3, "zeillinger_us": zeil3,
+                   "fused_rollout_list_semantics_us_per_episode": list3,
+                   "fused_rollout_zeillinger_host_us_per_episode": zroll3,
                    "binned_note": "the order of hk_generate_points_binned (groups of 64 games, strata of 16) with the "
                                   "permutation as game ids: the default route for batches of this shape that are rolled "
                                   "out from memory -- generate + bin is one launch; the fused compute_rho loop draws its "

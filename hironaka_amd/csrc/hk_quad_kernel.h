@@ -708,6 +708,192 @@ __device__ __forceinline__ void qd_ranks_lds(const float (&q)[R * D], float* cmi
   else qd_ranks_lds_t<M, CW, R, D, NB, kKeyLast, true>(q, cmine, j, rows_end, rank);
 }
 
+// ---- the domination test of a FRESH game on packed rows (many slots per lane: (50,4)) ----------------------------------
+// A fresh draw below 127 fits seven bits, so a row of up to four coordinates is ONE dword with a guard bit above every
+// field, and "a <= b in every coordinate" is one subtraction: no field of (b | H) - a borrows iff every b_k >= a_k, i.e.
+// iff all guard bits H = 0x80808080 survive -- v_sub, v_and, v_cmp where the float test takes ten instructions on four
+// registers per row.  A hole is 0x7F7F7F7F: above every row, dominated by all of them, dominating none.
+//   level 0: every lane's row of least coordinate sum (v_sad_u8) is a "champion"; the quad's four champions (DPP) are
+//            tested against all slots -- strict domination only, so a champion never removes itself or its twins.
+//            Domination is transitive and the result is the set of minimal rows (of equal rows the one of lowest rank),
+//            so a row may go as soon as ANY row dominates it.  Of 50 uniform rows in dimension 4 about 20 survive (30 in
+//            the widest of a wave's 16 games; the own-slot triangles of qd_newton_two_level leave 29 / 36);
+//   level 1: the survivors are parked at their rank among the survivors (rank order = row order: it decides between equal
+//            rows), re-dealt four ways, and every lane tests its slots against ALL of them (one broadcast read per
+//            row): removed iff dominated by a different row, or by an equal one of lower rank.  The verdicts return
+//            through a byte per survivor.
+// `sc`: the game's LDS scratch, 16-B aligned, M + 4 dwords + M bytes.  Equal to _jax_ops.py:15-73 on integer rows; `reposition` commutes with
+// it there (a column's minimum over the survivors is its minimum over all rows: a row holding it can only be dominated by
+// a row that holds it too), so the caller subtracts the minima afterwards, on the survivors' floats.
+constexpr uint32_t kPackGuard = 0x80808080u, kPackHole = 0x7F7F7F7Fu;
+constexpr int kPackMaxValue = 127;  // draws are < max_value: at most 126
+
+// rows [4 (C - 1), 4 C) of the parked survivors against the lane's slots, for C = 1 .. NB2: against such a row, slot
+// s < C - 1 is the EARLIER row (it goes only if the row is below it and different), slot s > C - 1 the later one (an
+// equal row removes it too), slot C - 1 is decided per row.  The verdicts accumulate as lane masks in scalar registers
+// (ballots: no vector instruction; as a bool per slot the compiler packed them into bytes of vector registers, ~30
+// instructions per row).
+typedef uint32_t vu4 __attribute__((ext_vector_type(4)));
+
+template <int NB2, int C>
+struct QgPackedSeg {
+  // `cur`: the segment's four rows (one 16-B read); the next segment's are requested before this one's tests.  Slot by
+  // slot: the four rows' verdicts on a slot meet in scalar lane masks and are folded into the slot's counter at once
+  // (one vector instruction per slot and segment; a lane mask per slot kept over the whole level overflows the scalar
+  // registers: 2 000 spills in the build that tried).
+  static __device__ __forceinline__ void run(const uint32_t (&w2)[NB2], const uint32_t (&g2)[NB2], uint32_t (&cnt)[NB2],
+                                             const uint32_t* sv, int np1, int rows, int j, vu4 cur) {
+    constexpr int r0 = kQuad * (C - 1);
+    if (rows <= r0) return;  // (wave-uniform)
+    vu4 nxt = cur;
+    if constexpr (C < NB2) nxt = *reinterpret_cast<const vu4*>(sv + kQuad * C);
+    uint32_t c[kQuad];
+#pragma unroll
+    for (int rr = 0; rr < kQuad; ++rr) c[rr] = (r0 + rr < np1) ? cur[rr] : kPackHole;  // (past np1: holes, dominating nothing)
+#pragma unroll
+    for (int s = 0; s < NB2; ++s) {
+      bool hit = false;
+#pragma unroll
+      for (int rr = 0; rr < kQuad; ++rr) {
+        const bool dom = ((g2[s] - c[rr]) & kPackGuard) == kPackGuard;  // row <= my slot s, coordinate by coordinate
+        if (s > C - 1) hit |= dom;                                      // my slot is the later row: equal rows count
+        else if (s < C - 1) hit |= dom & (w2[s] != c[rr]);              // ... the earlier row: different rows only
+        else hit |= dom & ((w2[s] != c[rr]) | (rr < j));                // ... decided by the ranks r0 + rr and r0 + j
+      }
+      cnt[s] += hit ? 1u : 0u;
+    }
+    if constexpr (C < NB2) QgPackedSeg<NB2, C + 1>::run(w2, g2, cnt, sv, np1, rows, j, nxt);
+  }
+};
+
+template <int NB2>
+__device__ __forceinline__ void qg_packed_level1(const uint32_t* sv, uint8_t* vd, int np1, int rows, int j, int lane) {
+  uint32_t w2[NB2], g2[NB2], cnt[NB2];
+  const vu4 first = *reinterpret_cast<const vu4*>(sv);
+#pragma unroll
+  for (int s = 0; s < NB2; ++s) {
+    const int r = kQuad * s + j;
+    const uint32_t v = sv[r < rows ? r : 0];
+    w2[s] = (r < np1) ? v : kPackHole;
+    g2[s] = w2[s] | kPackGuard;
+    cnt[s] = 0u;
+  }
+  QgPackedSeg<NB2, 1>::run(w2, g2, cnt, sv, np1, rows, j, first);  // (rows: wave-uniform, >= every game's np1)
+#pragma unroll
+  for (int s = 0; s < NB2; ++s) {
+    const int r = kQuad * s + j;
+    if (r < np1) vd[r] = cnt[s] ? (uint8_t)1 : (uint8_t)0;
+  }
+}
+
+// w[s]: the packed row of slot s < NB (a hole: kPackHole); q[] receives the survivors' floats (slots >= NB are not touched)
+template <int M, int D, int R, int NB>
+__device__ __forceinline__ void qg_newton_on_packed(float (&q)[R * D], uint32_t (&w)[NB], uint32_t* sc, int j, int lane) {
+  static_assert(D <= 4, "a row travels as four 7-bit fields");
+  // level 0: the quad's four champions against every slot
+  {
+    uint32_t bs = __builtin_amdgcn_sad_u8(w[0], 0u, 0u), bw = w[0];
+#pragma unroll
+    for (int s = 1; s < NB; ++s) {
+      const uint32_t ss = __builtin_amdgcn_sad_u8(w[s], 0u, 0u);
+      const bool lt = ss < bs;
+      bs = lt ? ss : bs;
+      bw = lt ? w[s] : bw;
+    }
+    const uint32_t c0 = bw, c1 = (uint32_t)qperm_i<kQuadUp1>((int)bw), c2 = (uint32_t)qperm_i<kQuadUp2>((int)bw),
+                   c3 = (uint32_t)qperm_i<kQuadUp3>((int)bw);
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+      const uint32_t g = w[s] | kPackGuard;
+      const bool r0 = (((g - c0) & kPackGuard) == kPackGuard) & (w[s] != c0);
+      const bool r1 = (((g - c1) & kPackGuard) == kPackGuard) & (w[s] != c1);
+      const bool r2 = (((g - c2) & kPackGuard) == kPackGuard) & (w[s] != c2);
+      const bool r3 = (((g - c3) & kPackGuard) == kPackGuard) & (w[s] != c3);
+      w[s] = (r0 | r1 | r2 | r3) ? kPackHole : w[s];
+    }
+  }
+  // the survivors to their ranks (popcounts of the four lanes' masks, hk_quadroll_kernel.h: qr_redeal)
+  uint32_t lm = 0;
+#pragma unroll
+  for (int s = 0; s < NB; ++s) lm |= (w[s] != kPackHole) ? (1u << s) : 0u;
+  const int np1 = q_sum(__popc(lm));
+  int s1 = NB;  // slots per lane at level 1: the wave-uniform maximum of ceil(np1 / 4)
+#pragma nounroll
+  while (s1 > 1 && !__any(np1 > kQuad * (s1 - 1))) --s1;
+  const uint32_t l1 = (uint32_t)qperm_i<kQuadUp1>((int)lm), l2 = (uint32_t)qperm_i<kQuadUp2>((int)lm),
+                 l3 = (uint32_t)qperm_i<kQuadUp3>((int)lm);
+  const bool b1 = ((j + 1) & 3) < j, b2 = ((j + 2) & 3) < j, b3 = ((j + 3) & 3) < j;
+  uint8_t* vd = reinterpret_cast<uint8_t*>(sc + M + 4);  // (segment reads run up to 3 dwords past the M rows)
+  int rk[NB];
+#pragma unroll
+  for (int s = 0; s < NB; ++s) {
+    const uint32_t below = (1u << s) - 1u, at = 1u << s;
+    rk[s] = __popc(lm & below) + __popc(l1 & (below | (b1 ? at : 0u))) + __popc(l2 & (below | (b2 ? at : 0u))) +
+            __popc(l3 & (below | (b3 ? at : 0u)));
+    if ((lm >> s) & 1u) sc[rk[s]] = w[s];
+  }
+  wave_lds_fence();
+  const int rows = (kQuad * s1 < M) ? kQuad * s1 : M;
+  // (buckets of slots per lane; 50 uniform rows in dimension 4: the widest of a wave's 16 games keeps 26 - 36 rows after
+  // level 0, 7 - 9 slots per lane)
+  if (s1 <= 2) qg_packed_level1<(NB < 2 ? NB : 2)>(sc, vd, np1, rows, j, lane);
+  else if (s1 <= 4) qg_packed_level1<(NB < 4 ? NB : 4)>(sc, vd, np1, rows, j, lane);
+  else if (s1 <= 6) qg_packed_level1<(NB < 6 ? NB : 6)>(sc, vd, np1, rows, j, lane);
+  else if (s1 <= 7) qg_packed_level1<(NB < 7 ? NB : 7)>(sc, vd, np1, rows, j, lane);
+  else if (s1 <= 8) qg_packed_level1<(NB < 8 ? NB : 8)>(sc, vd, np1, rows, j, lane);
+  else if (s1 <= 9) qg_packed_level1<(NB < 9 ? NB : 9)>(sc, vd, np1, rows, j, lane);
+  else if (s1 <= 10) qg_packed_level1<(NB < 10 ? NB : 10)>(sc, vd, np1, rows, j, lane);
+  else qg_packed_level1<NB>(sc, vd, np1, rows, j, lane);
+  wave_lds_fence();
+  // the survivors' floats from their packed words (v_cvt_f32_ubyteN: exact): q[] is written here and nowhere read since
+  // the packing -- its R * D registers are free during the whole test (inside a rollout kernel's 168-register budget
+  // they were what spilled)
+#pragma unroll
+  for (int s = 0; s < NB; ++s) {
+    const bool kept = ((lm >> s) & 1u) && vd[((lm >> s) & 1u) ? rk[s] : 0] == 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) q[s * D + k] = kept ? (float)((w[s] >> (8 * k)) & 0xFFu) : INFINITY;
+  }
+  wave_lds_fence();  // (the scratch is the game's image again)
+}
+
+// a FRESH game (the generator: draws below 127, every value integral): pack, test
+template <int M, int D, int R>
+__device__ __forceinline__ void qg_newton_packed(float (&q)[R * D], uint32_t* sc, int j, int lane) {
+  uint32_t w[R];
+#pragma unroll
+  for (int s = 0; s < R; ++s) {
+    uint32_t v = (uint32_t)q[s * D];
+#pragma unroll
+    for (int k = 1; k < D; ++k) v |= (uint32_t)q[s * D + k] << (8 * k);
+    w[s] = (q[s * D] < INFINITY) ? v : kPackHole;
+  }
+  qg_newton_on_packed<M, D, R, R>(q, w, sc, j, lane);
+}
+
+// ANY state (hk_step on many slots per lane): w[s] = the packed row of slot s, true (wave-uniform) iff every live coordinate
+// of the wave is integral and at most 126 -- fract() of all of them is zero (a hole's is NaN or 0: the maximum skips
+// it), no saturating conversion reaches a guard bit.
+template <int R, int D, int NB>
+__device__ __forceinline__ bool qd_pack_rows(const float (&q)[R * D], uint32_t (&w)[NB]) {
+  static_assert(D <= 4, "four fields");
+  uint32_t bad = 0u;
+  float fr = 0.0f;
+#pragma unroll
+  for (int s = 0; s < NB; ++s) {
+    uint32_t raw = 0u;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      raw = __builtin_amdgcn_cvt_pk_u8_f32(q[s * D + k], k, raw);
+      fr = __builtin_fmaxf(fr, __builtin_amdgcn_fractf(q[s * D + k]));
+    }
+    const bool live = q[s * D] < INFINITY;
+    bad |= live ? (raw | (raw + 0x01010101u)) : 0u;
+    w[s] = live ? raw : kPackHole;
+  }
+  return !__any(((bad & kPackGuard) != 0u) | (fr > 0.0f));
+}
+
 // one transition on slots [0, NB) of the four lanes; returns the GAME's number of live rows.  `sorted` (list
 // semantics): the survivors are ranked right after the Newton stage, before a rescale could round two keys together.
 // AUX: the kernel may be asked for the sorted observation features of many slots per lane (the run-time configured
@@ -721,8 +907,19 @@ __device__ __forceinline__ int qd_stages(float (&q)[R * D], const float (&c)[D],
   if (stages & HK_STAGE_REPOSITION) qd_reposition<R, D, NB>(q, flags);
   if (stages & HK_STAGE_NEWTON) {
     if constexpr (NB > kQuadDppSlots) {
-      if (tsc) qd_newton_two_level<M, CW, R, D, NB>(q, cmine, tsc, j, slots_end);
-      else qd_newton_lds<M, CW, R, D, NB>(q, cmine, j, slots_end);
+      // many slots per lane (states no Newton pass has thinned): integral rows of small coordinates -- what a generator's
+      // raw draws are after a shift and the reposition -- take the test on packed rows (the game's parked-row region is
+      // its scratch), anything else the float tests
+      bool packed = false;
+      if constexpr (D <= 4) {
+        uint32_t w[NB];
+        packed = qd_pack_rows<R, D, NB>(q, w);
+        if (packed) qg_newton_on_packed<M, D, R, NB>(q, w, reinterpret_cast<uint32_t*>(cmine), j, 0);
+      }
+      if (!packed) {
+        if (tsc) qd_newton_two_level<M, CW, R, D, NB>(q, cmine, tsc, j, slots_end);
+        else qd_newton_lds<M, CW, R, D, NB>(q, cmine, j, slots_end);
+      }
     } else {
       qd_newton<R, D, NB>(q, j);
     }

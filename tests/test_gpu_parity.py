@@ -601,6 +601,44 @@ def test_reordered_batch_with_game_ids_rolls_out_like_the_original(spec):
                     assert np.array_equal(host(got["done_count"]).astype(np.uint64), want["done_count"])
 
 
+@pytest.mark.parametrize("spec", [(50, 4), (40, 3), (33, 4)])
+def test_dense_states_of_large_games_packed_and_float_tests_match_oracle(spec):
+    """hk_step on states no Newton pass has thinned (more than 8 slots per lane): integral rows whose coordinates stay
+    below 127 after the shift and the reposition take the domination test on packed rows (`qg_newton_on_packed`),
+    anything else -- a coordinate of 127 and more, fractional rows, a mix inside one wave -- the float tests.  Every
+    variant against the oracle: value ranges around the packing limit, duplicates (small ranges), holes, every stage
+    subset with a Newton stage, three semantics."""
+    m, d = spec
+    rng = np.random.default_rng(11 * m + d)
+    b = 16 * 5 + 3
+    cls = rng.integers(0, 2 ** d - d - 1, b).astype(np.int32)
+    ax = rng.integers(0, d, b).astype(np.int32)
+    cases = {}
+    for maxv in (2, 4, 20, 32, 43, 64, 127, 128, 1000):
+        cases[f"int{maxv}"] = rng.integers(0, maxv, (b, m, d)).astype(np.float32)
+    cases["at_the_limit"] = rng.integers(120, 128, (b, m, d)).astype(np.float32)
+    cases["fractional"] = (rng.integers(0, 40, (b, m, d)) / np.float32(8)).astype(np.float32)
+    mixed = rng.integers(0, 20, (b, m, d)).astype(np.float32)
+    mixed[5, 3, 1] = 0.5       # one fractional coordinate in the batch: its wave takes the float test
+    mixed[40, 7, 0] = 300.0    # one coordinate past the limit
+    cases["mixed"] = mixed
+    holes = rng.integers(0, 20, (b, m, d)).astype(np.float32)
+    holes[rng.random((b, m)) < 0.15] = -1.0
+    cases["holes"] = holes
+    for name, p in cases.items():
+        for sem in ("jax", "torch", "list"):
+            fl_o = CO.flags_of(sem=sem, noop_if_invalid=sem != "jax", ignore_ended=sem == "torch")
+            fl_p = ops.make_flags(sem, sem != "jax", sem == "torch")
+            for stages in (4, 6, 7, 15):
+                want = CO.step(p, cls, ax, stages=stages, flags=fl_o)
+                for fam in (0, A.HK_FLAG_FORCE_FOUR_LANES):
+                    if fam and (m, d) != (50, 4):  # (the shapes without a four-lane step kernel: the default route only)
+                        continue
+                    got = ops.step(dev(p), dev(cls), dev(ax), stages=stages, flags=fl_p | fam, want=("done", "num_points"))
+                    assert np.array_equal(host(got["points"]), want["points"]), (name, sem, stages, fam)
+                    assert np.array_equal(host(got["num_points"]), want["num_points"]), (name, sem, stages, fam)
+
+
 @pytest.mark.parametrize("spec", [(10, 3), (20, 3), (20, 4), (50, 4)])
 def test_sorted_plain_rollouts_on_four_lanes_match_oracle(spec):
     """list semantics / COMPACT_SORTED on the four-lane rollout kernel (`quadroll_kernel<..., kHotList>`): the state is
