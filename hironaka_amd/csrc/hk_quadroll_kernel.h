@@ -329,24 +329,51 @@ __device__ __forceinline__ int qr_zeillinger(const float (&q)[R * D], float* cmi
   int n = (kQuad * smax < M) ? kQuad * smax : M;
 #pragma nounroll
   for (int t = 0; t < kQuad - 1 && n > 2 && !__any(np >= n); ++t) --n;
+  // The pairs i < jj < n in COLUMN-major order (position jj (jj - 1) / 2 + i), lane j taking every fourth position from
+  // j on -- every lane the same number of pairs, whatever n (row-wise, lane j took the rows i = j, j + 4, ... against all
+  // later rows: the inner loops ran in lockstep for the longest of the four, 55 passes of pairs where 47.5 are due at
+  // n = 20).  A step of four positions wraps at most once from column 4 on; the six pairs of the columns 1 .. 3 go
+  // first.  Two positions per pass, a best of its own each (two independent chains; the pair's index is part of the
+  // key, so the order of the merges does not matter).
   ZeilBest<D> best, second;
-#pragma nounroll
-  for (int i = j; i + 1 < n; i += kQuad) {
-    float pi[D];
+  auto pair = [&](ZeilBest<D>& bst, int i, int jj, auto checked, bool ok) {
+    float pi[D], pj[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) pi[k] = cmine[i * CW + k];
-#pragma nounroll
-    for (int jj = i + 1; jj < n; jj += 2) {
-      float pj[D], pk[D];
-      const int j2 = (jj + 1 < n) ? jj + 1 : jj;
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        pj[k] = cmine[jj * CW + k];
-        pk[k] = cmine[j2 * CW + k];
-      }
-      zeil_pair<D, false, false>(best, pi, pj, true, 64 * i + jj);
-      zeil_pair<D, false, false>(second, pi, pk, true, 64 * i + jj + 1);  // (past the end: the last pair again, later)
+    for (int k = 0; k < D; ++k) {
+      pi[k] = cmine[i * CW + k];
+      pj[k] = cmine[jj * CW + k];
     }
+    zeil_pair<D, false, decltype(checked)::value>(bst, pi, pj, ok, 64 * i + jj);
+  };
+  {
+    const int ia = (j == 2) ? 1 : 0, ja = (j == 0) ? 1 : ((j == 3) ? 3 : 2);  // (0,1) (0,2) (1,2) (0,3)
+    const bool oka = ja < n;
+    pair(best, ia, oka ? ja : 0, std::true_type{}, oka);
+    const bool okb = j < 2 && 3 < n;                                           // (1,3) (2,3)
+    pair(second, okb ? j + 1 : 0, okb ? 3 : 0, std::true_type{}, okb);
+  }
+  const int rest = n >= 5 ? n * (n - 1) / 2 - 6 : 0;  // the pairs of the columns >= 4
+  const int passes = (rest + 2 * kQuad - 1) / (2 * kQuad);
+  int i = j, jj = 4;
+  auto advance = [&]() {
+    i += kQuad;
+    const bool wrap = i >= jj;
+    i = wrap ? i - jj : i;
+    jj += wrap ? 1 : 0;
+  };
+#pragma nounroll
+  for (int t = 0; t + 1 < passes; ++t) {  // (all but the last pass: every position exists)
+    pair(best, i, jj, std::false_type{}, true);
+    advance();
+    pair(second, i, jj, std::false_type{}, true);
+    advance();
+  }
+  if (passes > 0) {
+    const bool ok1 = jj < n;
+    pair(best, ok1 ? i : 0, ok1 ? jj : 0, std::true_type{}, ok1);
+    advance();
+    const bool ok2 = jj < n;
+    pair(second, ok2 ? i : 0, ok2 ? jj : 0, std::true_type{}, ok2);
   }
   zeil_merge<D, false>(best, second);
   {
