@@ -469,6 +469,7 @@ __device__ __forceinline__ int duo_zeillinger(const float (&q)[CH * D], int h, f
   }
   {  // the partner's best
     ZeilBest<D> o;
+    zeil_dpp_safe<D, KEEP>(best);
     o.hi = (uint32_t)duo_other_i((int)best.hi);
     o.lo = (uint32_t)duo_other_i((int)best.lo);
     if constexpr (KEEP) {

@@ -540,16 +540,23 @@ __device__ __forceinline__ int c_zeillinger(const float (&q)[C * D], int nmax, b
 
 // ---- multi-word unsigned compares as borrow chains (v_subb_co, the borrow travelling in a scalar register pair), their
 // results added to counters (v_addc_co) or selecting (v_cndmask) without a detour through scalar and/or logic ----------
+// Inline asm, because the compiler turns every C++ spelling of a borrow chain (__builtin_subc, 128-bit subtraction with
+// overflow) back into compares -- and the 64-bit compares it makes of it are slower here than what they replace
+// (measured: hk_get_features at (50,4) 137 us against 85, dense states 926 against 177).  gfx950 wants two wait states
+// between a vector instruction that WRITES a scalar register and a vector instruction that reads it, and the
+// compiler's hazard recogniser does not look into inline asm: every instruction below that reads a lane mask waits
+// for itself (s_nop 1), whatever the scheduler put before it.  Their VGPR results are never read through DPP without
+// a compiler-generated instruction in between (kb_dpp_safe where one would be).
 using LaneMask = uint64_t;
 __device__ __forceinline__ LaneMask kb_subb(uint32_t mine, uint32_t other, LaneMask borrow_in) {
   uint32_t diff;
   LaneMask borrow;
-  asm("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(diff), "=s"(borrow) : "v"(mine), "v"(other), "s"(borrow_in));
+  asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(diff), "=s"(borrow) : "v"(mine), "v"(other), "s"(borrow_in));
   return borrow;
 }
 __device__ __forceinline__ void kb_count(uint32_t& n, LaneMask c) {
   LaneMask carry;
-  asm("v_addc_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(n), "=s"(carry) : "s"(c));
+  asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(n), "=s"(carry) : "s"(c));
 }
 // lanes where `other` comes first: other > mine, or other == mine on the lanes of `tie` (words: least significant first)
 template <int W>
@@ -561,12 +568,15 @@ __device__ __forceinline__ LaneMask key_other_first(const uint32_t (&mine)[W], c
 }
 __device__ __forceinline__ uint32_t kb_select(uint32_t keep, uint32_t take, LaneMask c) {
   uint32_t r;
-  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(keep), "v"(take), "s"(c));
+  asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(keep), "v"(take), "s"(c));
   return r;
 }
 __device__ __forceinline__ float kb_select(float keep, float take, LaneMask c) {
   return __uint_as_float(kb_select(__float_as_uint(keep), __float_as_uint(take), c));
 }
+// a value one of the instructions above produced, before a DPP instruction reads it (two wait states there too)
+__device__ __forceinline__ void kb_dpp_safe(uint32_t& x) { asm volatile("s_nop 1" : "+v"(x)); }
+__device__ __forceinline__ void kb_dpp_safe(float& x) { asm volatile("s_nop 1" : "+v"(x)); }
 
 // ---- Zeillinger's pair test for the kernels that split a game over lanes (hk_duo_kernel.h, hk_quadroll_kernel.h) ------
 // The best pair so far as ONE comparable key: hi = the bits of L (a non-negative finite float: its bit pattern orders
@@ -628,6 +638,17 @@ __device__ __forceinline__ void zeil_pair(ZeilBest<D>& best, const float* mine, 
   if constexpr (KEEP) {
 #pragma unroll
     for (int k = 0; k < D; ++k) best.bd[k] = kb_select(best.bd[k], v[k], better);
+  }
+}
+
+// before the best so far travels to another lane through DPP
+template <int D, bool KEEP>
+__device__ __forceinline__ void zeil_dpp_safe(ZeilBest<D>& best) {
+  kb_dpp_safe(best.hi);
+  kb_dpp_safe(best.lo);
+  if constexpr (KEEP) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) kb_dpp_safe(best.bd[k]);
   }
 }
 

@@ -378,9 +378,11 @@ __device__ __forceinline__ int qr_zeillinger(const float (&q)[R * D], float* cmi
   zeil_merge<D, false>(best, second);
   {
     ZeilBest<D> o;
+    zeil_dpp_safe<D, false>(best);
     o.hi = (uint32_t)qperm_i<kQuadUp1>((int)best.hi);
     o.lo = (uint32_t)qperm_i<kQuadUp1>((int)best.lo);
     zeil_merge<D, false>(best, o);
+    zeil_dpp_safe<D, false>(best);
     o.hi = (uint32_t)qperm_i<kQuadUp2>((int)best.hi);
     o.lo = (uint32_t)qperm_i<kQuadUp2>((int)best.lo);
     zeil_merge<D, false>(best, o);
