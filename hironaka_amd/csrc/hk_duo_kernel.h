@@ -430,10 +430,10 @@ __device__ __forceinline__ int duo_zeillinger(const float (&q)[CH * D], int h, f
     for (int a = 0; a < NB; ++a) {
 #pragma unroll
       for (int b = a + 1; b < NB; ++b)
-        zeil_pair<D, true, false>(best, &q[a * D], &q[b * D], true, (128 * a + 2 * b) + 65 * h);
+        zeil_pair_cmp<D, true, false>(best, &q[a * D], &q[b * D], true, (128 * a + 2 * b) + 65 * h);
 #pragma unroll
       for (int b = a; b < NB; ++b)
-        zeil_pair<D, true>(best, &q[a * D], &p[b * D], (b > a) | (h == 0), (128 * a + 2 * b + 1) + 63 * h);
+        zeil_pair_cmp<D, true>(best, &q[a * D], &p[b * D], (b > a) | (h == 0), (128 * a + 2 * b + 1) + 63 * h);
       if constexpr (NB > 3) __builtin_amdgcn_sched_barrier(0);
     }
   } else {
@@ -461,15 +461,13 @@ __device__ __forceinline__ int duo_zeillinger(const float (&q)[CH * D], int h, f
           pj[k] = mine[j * D + k];
           pk[k] = mine[j2 * D + k];
         }
-        zeil_pair<D, false, false>(best, pi, pj, true, 64 * i + j);
-        zeil_pair<D, false, false>(second, pi, pk, true, 64 * i + j + 1);  // (past the end: the last pair again, later)
+        zeil_pair2<D>(best, second, pi, pj, 64 * i + j, pi, pk, 64 * i + j + 1);  // (past the end: the last pair again, later)
       }
     }
     zeil_merge<D, false>(best, second);
   }
   {  // the partner's best
     ZeilBest<D> o;
-    zeil_dpp_safe<D, KEEP>(best);
     o.hi = (uint32_t)duo_other_i((int)best.hi);
     o.lo = (uint32_t)duo_other_i((int)best.lo);
     if constexpr (KEEP) {

@@ -545,8 +545,9 @@ __device__ __forceinline__ int c_zeillinger(const float (&q)[C * D], int nmax, b
 // (measured: hk_get_features at (50,4) 137 us against 85, dense states 926 against 177).  gfx950 wants two wait states
 // between a vector instruction that WRITES a scalar register and a vector instruction that reads it, and the
 // compiler's hazard recogniser does not look into inline asm: every instruction below that reads a lane mask waits
-// for itself (s_nop 1), whatever the scheduler put before it.  Their VGPR results are never read through DPP without
-// a compiler-generated instruction in between (kb_dpp_safe where one would be).
+// for itself (s_nop 1), whatever the scheduler put before it -- or sits in a block whose order provides the distance
+// (kb_rank3 / kb_rank2 / zeil_pair2).  Their VGPR results are never read through DPP without a compiler-generated
+// instruction in between (zeil_merge is plain C++ for that reason); scripts/check_sgpr_hazards.py scans a listing.
 using LaneMask = uint64_t;
 __device__ __forceinline__ LaneMask kb_subb(uint32_t mine, uint32_t other, LaneMask borrow_in) {
   uint32_t diff;
@@ -574,9 +575,239 @@ __device__ __forceinline__ uint32_t kb_select(uint32_t keep, uint32_t take, Lane
 __device__ __forceinline__ float kb_select(float keep, float take, LaneMask c) {
   return __uint_as_float(kb_select(__float_as_uint(keep), __float_as_uint(take), c));
 }
-// a value one of the instructions above produced, before a DPP instruction reads it (two wait states there too)
-__device__ __forceinline__ void kb_dpp_safe(uint32_t& x) { asm volatile("s_nop 1" : "+v"(x)); }
-__device__ __forceinline__ void kb_dpp_safe(float& x) { asm volatile("s_nop 1" : "+v"(x)); }
+// Three (two) chains against the SAME other row, interleaved link by link, and their counts, as one block: a link reads
+// the borrow its chain wrote three (two + s_nop 0) instructions earlier, a count the borrow of a chain that ended two
+// instructions before it -- the two wait states are in the order of the instructions, no s_nop per instruction.
+// r?: += (other comes before m?);  w (SHARED): += all of them (what the other row "won").
+template <int W, bool SHARED>
+__device__ __forceinline__ void kb_rank3(const uint32_t (&o)[W], const uint32_t (&mA)[W], const uint32_t (&mB)[W],
+                                         const uint32_t (&mC)[W], LaneMask tA, LaneMask tB, LaneMask tC, uint32_t& rA,
+                                         uint32_t& rB, uint32_t& rC, uint32_t& w) {
+  uint32_t j;
+  LaneMask x, cA, cB, cC;
+  static_assert(W == 1 || W == 3 || W == 4, "keys of one, three or four words");
+  if constexpr (W == 1 && SHARED)
+    asm("s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA0], %[o0], %[tA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB0], %[o0], %[tB]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cC], %[mC0], %[o0], %[tC]\n\t"
+        "v_addc_co_u32_e64 %[rA], %[x], 0, %[rA], %[cA]\n\t"
+        "v_addc_co_u32_e64 %[rB], %[x], 0, %[rB], %[cB]\n\t"
+        "v_addc_co_u32_e64 %[rC], %[x], 0, %[rC], %[cC]\n\t"
+        "v_addc_co_u32_e64 %[w], %[x], 0, %[w], %[cA]\n\t"
+        "v_addc_co_u32_e64 %[w], %[x], 0, %[w], %[cB]\n\t"
+        "v_addc_co_u32_e64 %[w], %[x], 0, %[w], %[cC]\n\t"
+        : [rA] "+v"(rA), [rB] "+v"(rB), [rC] "+v"(rC), [w] "+v"(w), [j] "=&v"(j), [x] "=&s"(x), [cA] "=&s"(cA), [cB] "=&s"(cB), [cC] "=&s"(cC)
+        : [o0] "v"(o[0]), [mA0] "v"(mA[0]), [mB0] "v"(mB[0]), [mC0] "v"(mC[0]), [tA] "s"(tA), [tB] "s"(tB), [tC] "s"(tC));
+  else if constexpr (W == 1 && !SHARED)
+    asm("s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA0], %[o0], %[tA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB0], %[o0], %[tB]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cC], %[mC0], %[o0], %[tC]\n\t"
+        "v_addc_co_u32_e64 %[rA], %[x], 0, %[rA], %[cA]\n\t"
+        "v_addc_co_u32_e64 %[rB], %[x], 0, %[rB], %[cB]\n\t"
+        "v_addc_co_u32_e64 %[rC], %[x], 0, %[rC], %[cC]\n\t"
+        : [rA] "+v"(rA), [rB] "+v"(rB), [rC] "+v"(rC), [j] "=&v"(j), [x] "=&s"(x), [cA] "=&s"(cA), [cB] "=&s"(cB), [cC] "=&s"(cC)
+        : [o0] "v"(o[0]), [mA0] "v"(mA[0]), [mB0] "v"(mB[0]), [mC0] "v"(mC[0]), [tA] "s"(tA), [tB] "s"(tB), [tC] "s"(tC));
+  else if constexpr (W == 3 && SHARED)
+    asm("s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA0], %[o0], %[tA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB0], %[o0], %[tB]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cC], %[mC0], %[o0], %[tC]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA1], %[o1], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB1], %[o1], %[cB]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cC], %[mC1], %[o1], %[cC]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA2], %[o2], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB2], %[o2], %[cB]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cC], %[mC2], %[o2], %[cC]\n\t"
+        "v_addc_co_u32_e64 %[rA], %[x], 0, %[rA], %[cA]\n\t"
+        "v_addc_co_u32_e64 %[rB], %[x], 0, %[rB], %[cB]\n\t"
+        "v_addc_co_u32_e64 %[rC], %[x], 0, %[rC], %[cC]\n\t"
+        "v_addc_co_u32_e64 %[w], %[x], 0, %[w], %[cA]\n\t"
+        "v_addc_co_u32_e64 %[w], %[x], 0, %[w], %[cB]\n\t"
+        "v_addc_co_u32_e64 %[w], %[x], 0, %[w], %[cC]\n\t"
+        : [rA] "+v"(rA), [rB] "+v"(rB), [rC] "+v"(rC), [w] "+v"(w), [j] "=&v"(j), [x] "=&s"(x), [cA] "=&s"(cA), [cB] "=&s"(cB), [cC] "=&s"(cC)
+        : [o0] "v"(o[0]), [o1] "v"(o[1]), [o2] "v"(o[2]), [mA0] "v"(mA[0]), [mA1] "v"(mA[1]), [mA2] "v"(mA[2]), [mB0] "v"(mB[0]), [mB1] "v"(mB[1]), [mB2] "v"(mB[2]), [mC0] "v"(mC[0]), [mC1] "v"(mC[1]), [mC2] "v"(mC[2]), [tA] "s"(tA), [tB] "s"(tB), [tC] "s"(tC));
+  else if constexpr (W == 3 && !SHARED)
+    asm("s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA0], %[o0], %[tA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB0], %[o0], %[tB]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cC], %[mC0], %[o0], %[tC]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA1], %[o1], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB1], %[o1], %[cB]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cC], %[mC1], %[o1], %[cC]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA2], %[o2], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB2], %[o2], %[cB]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cC], %[mC2], %[o2], %[cC]\n\t"
+        "v_addc_co_u32_e64 %[rA], %[x], 0, %[rA], %[cA]\n\t"
+        "v_addc_co_u32_e64 %[rB], %[x], 0, %[rB], %[cB]\n\t"
+        "v_addc_co_u32_e64 %[rC], %[x], 0, %[rC], %[cC]\n\t"
+        : [rA] "+v"(rA), [rB] "+v"(rB), [rC] "+v"(rC), [j] "=&v"(j), [x] "=&s"(x), [cA] "=&s"(cA), [cB] "=&s"(cB), [cC] "=&s"(cC)
+        : [o0] "v"(o[0]), [o1] "v"(o[1]), [o2] "v"(o[2]), [mA0] "v"(mA[0]), [mA1] "v"(mA[1]), [mA2] "v"(mA[2]), [mB0] "v"(mB[0]), [mB1] "v"(mB[1]), [mB2] "v"(mB[2]), [mC0] "v"(mC[0]), [mC1] "v"(mC[1]), [mC2] "v"(mC[2]), [tA] "s"(tA), [tB] "s"(tB), [tC] "s"(tC));
+  else if constexpr (W == 4 && SHARED)
+    asm("s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA0], %[o0], %[tA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB0], %[o0], %[tB]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cC], %[mC0], %[o0], %[tC]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA1], %[o1], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB1], %[o1], %[cB]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cC], %[mC1], %[o1], %[cC]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA2], %[o2], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB2], %[o2], %[cB]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cC], %[mC2], %[o2], %[cC]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA3], %[o3], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB3], %[o3], %[cB]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cC], %[mC3], %[o3], %[cC]\n\t"
+        "v_addc_co_u32_e64 %[rA], %[x], 0, %[rA], %[cA]\n\t"
+        "v_addc_co_u32_e64 %[rB], %[x], 0, %[rB], %[cB]\n\t"
+        "v_addc_co_u32_e64 %[rC], %[x], 0, %[rC], %[cC]\n\t"
+        "v_addc_co_u32_e64 %[w], %[x], 0, %[w], %[cA]\n\t"
+        "v_addc_co_u32_e64 %[w], %[x], 0, %[w], %[cB]\n\t"
+        "v_addc_co_u32_e64 %[w], %[x], 0, %[w], %[cC]\n\t"
+        : [rA] "+v"(rA), [rB] "+v"(rB), [rC] "+v"(rC), [w] "+v"(w), [j] "=&v"(j), [x] "=&s"(x), [cA] "=&s"(cA), [cB] "=&s"(cB), [cC] "=&s"(cC)
+        : [o0] "v"(o[0]), [o1] "v"(o[1]), [o2] "v"(o[2]), [o3] "v"(o[3]), [mA0] "v"(mA[0]), [mA1] "v"(mA[1]), [mA2] "v"(mA[2]), [mA3] "v"(mA[3]), [mB0] "v"(mB[0]), [mB1] "v"(mB[1]), [mB2] "v"(mB[2]), [mB3] "v"(mB[3]), [mC0] "v"(mC[0]), [mC1] "v"(mC[1]), [mC2] "v"(mC[2]), [mC3] "v"(mC[3]), [tA] "s"(tA), [tB] "s"(tB), [tC] "s"(tC));
+  else if constexpr (W == 4 && !SHARED)
+    asm("s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA0], %[o0], %[tA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB0], %[o0], %[tB]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cC], %[mC0], %[o0], %[tC]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA1], %[o1], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB1], %[o1], %[cB]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cC], %[mC1], %[o1], %[cC]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA2], %[o2], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB2], %[o2], %[cB]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cC], %[mC2], %[o2], %[cC]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA3], %[o3], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB3], %[o3], %[cB]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cC], %[mC3], %[o3], %[cC]\n\t"
+        "v_addc_co_u32_e64 %[rA], %[x], 0, %[rA], %[cA]\n\t"
+        "v_addc_co_u32_e64 %[rB], %[x], 0, %[rB], %[cB]\n\t"
+        "v_addc_co_u32_e64 %[rC], %[x], 0, %[rC], %[cC]\n\t"
+        : [rA] "+v"(rA), [rB] "+v"(rB), [rC] "+v"(rC), [j] "=&v"(j), [x] "=&s"(x), [cA] "=&s"(cA), [cB] "=&s"(cB), [cC] "=&s"(cC)
+        : [o0] "v"(o[0]), [o1] "v"(o[1]), [o2] "v"(o[2]), [o3] "v"(o[3]), [mA0] "v"(mA[0]), [mA1] "v"(mA[1]), [mA2] "v"(mA[2]), [mA3] "v"(mA[3]), [mB0] "v"(mB[0]), [mB1] "v"(mB[1]), [mB2] "v"(mB[2]), [mB3] "v"(mB[3]), [mC0] "v"(mC[0]), [mC1] "v"(mC[1]), [mC2] "v"(mC[2]), [mC3] "v"(mC[3]), [tA] "s"(tA), [tB] "s"(tB), [tC] "s"(tC));
+}
+template <int W, bool SHARED>
+__device__ __forceinline__ void kb_rank2(const uint32_t (&o)[W], const uint32_t (&mA)[W], const uint32_t (&mB)[W],
+                                         LaneMask tA, LaneMask tB, uint32_t& rA, uint32_t& rB, uint32_t& w) {
+  uint32_t j;
+  LaneMask x, cA, cB;
+  static_assert(W == 1 || W == 3 || W == 4, "keys of one, three or four words");
+  if constexpr (W == 1 && SHARED)
+    asm("s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA0], %[o0], %[tA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB0], %[o0], %[tB]\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %[rA], %[x], 0, %[rA], %[cA]\n\t"
+        "v_addc_co_u32_e64 %[rB], %[x], 0, %[rB], %[cB]\n\t"
+        "v_addc_co_u32_e64 %[w], %[x], 0, %[w], %[cA]\n\t"
+        "v_addc_co_u32_e64 %[w], %[x], 0, %[w], %[cB]\n\t"
+        : [rA] "+v"(rA), [rB] "+v"(rB), [w] "+v"(w), [j] "=&v"(j), [x] "=&s"(x), [cA] "=&s"(cA), [cB] "=&s"(cB)
+        : [o0] "v"(o[0]), [mA0] "v"(mA[0]), [mB0] "v"(mB[0]), [tA] "s"(tA), [tB] "s"(tB));
+  else if constexpr (W == 1 && !SHARED)
+    asm("s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA0], %[o0], %[tA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB0], %[o0], %[tB]\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %[rA], %[x], 0, %[rA], %[cA]\n\t"
+        "v_addc_co_u32_e64 %[rB], %[x], 0, %[rB], %[cB]\n\t"
+        : [rA] "+v"(rA), [rB] "+v"(rB), [j] "=&v"(j), [x] "=&s"(x), [cA] "=&s"(cA), [cB] "=&s"(cB)
+        : [o0] "v"(o[0]), [mA0] "v"(mA[0]), [mB0] "v"(mB[0]), [tA] "s"(tA), [tB] "s"(tB));
+  else if constexpr (W == 3 && SHARED)
+    asm("s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA0], %[o0], %[tA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB0], %[o0], %[tB]\n\t"
+        "s_nop 0\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA1], %[o1], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB1], %[o1], %[cB]\n\t"
+        "s_nop 0\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA2], %[o2], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB2], %[o2], %[cB]\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %[rA], %[x], 0, %[rA], %[cA]\n\t"
+        "v_addc_co_u32_e64 %[rB], %[x], 0, %[rB], %[cB]\n\t"
+        "v_addc_co_u32_e64 %[w], %[x], 0, %[w], %[cA]\n\t"
+        "v_addc_co_u32_e64 %[w], %[x], 0, %[w], %[cB]\n\t"
+        : [rA] "+v"(rA), [rB] "+v"(rB), [w] "+v"(w), [j] "=&v"(j), [x] "=&s"(x), [cA] "=&s"(cA), [cB] "=&s"(cB)
+        : [o0] "v"(o[0]), [o1] "v"(o[1]), [o2] "v"(o[2]), [mA0] "v"(mA[0]), [mA1] "v"(mA[1]), [mA2] "v"(mA[2]), [mB0] "v"(mB[0]), [mB1] "v"(mB[1]), [mB2] "v"(mB[2]), [tA] "s"(tA), [tB] "s"(tB));
+  else if constexpr (W == 3 && !SHARED)
+    asm("s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA0], %[o0], %[tA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB0], %[o0], %[tB]\n\t"
+        "s_nop 0\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA1], %[o1], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB1], %[o1], %[cB]\n\t"
+        "s_nop 0\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA2], %[o2], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB2], %[o2], %[cB]\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %[rA], %[x], 0, %[rA], %[cA]\n\t"
+        "v_addc_co_u32_e64 %[rB], %[x], 0, %[rB], %[cB]\n\t"
+        : [rA] "+v"(rA), [rB] "+v"(rB), [j] "=&v"(j), [x] "=&s"(x), [cA] "=&s"(cA), [cB] "=&s"(cB)
+        : [o0] "v"(o[0]), [o1] "v"(o[1]), [o2] "v"(o[2]), [mA0] "v"(mA[0]), [mA1] "v"(mA[1]), [mA2] "v"(mA[2]), [mB0] "v"(mB[0]), [mB1] "v"(mB[1]), [mB2] "v"(mB[2]), [tA] "s"(tA), [tB] "s"(tB));
+  else if constexpr (W == 4 && SHARED)
+    asm("s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA0], %[o0], %[tA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB0], %[o0], %[tB]\n\t"
+        "s_nop 0\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA1], %[o1], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB1], %[o1], %[cB]\n\t"
+        "s_nop 0\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA2], %[o2], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB2], %[o2], %[cB]\n\t"
+        "s_nop 0\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA3], %[o3], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB3], %[o3], %[cB]\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %[rA], %[x], 0, %[rA], %[cA]\n\t"
+        "v_addc_co_u32_e64 %[rB], %[x], 0, %[rB], %[cB]\n\t"
+        "v_addc_co_u32_e64 %[w], %[x], 0, %[w], %[cA]\n\t"
+        "v_addc_co_u32_e64 %[w], %[x], 0, %[w], %[cB]\n\t"
+        : [rA] "+v"(rA), [rB] "+v"(rB), [w] "+v"(w), [j] "=&v"(j), [x] "=&s"(x), [cA] "=&s"(cA), [cB] "=&s"(cB)
+        : [o0] "v"(o[0]), [o1] "v"(o[1]), [o2] "v"(o[2]), [o3] "v"(o[3]), [mA0] "v"(mA[0]), [mA1] "v"(mA[1]), [mA2] "v"(mA[2]), [mA3] "v"(mA[3]), [mB0] "v"(mB[0]), [mB1] "v"(mB[1]), [mB2] "v"(mB[2]), [mB3] "v"(mB[3]), [tA] "s"(tA), [tB] "s"(tB));
+  else if constexpr (W == 4 && !SHARED)
+    asm("s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA0], %[o0], %[tA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB0], %[o0], %[tB]\n\t"
+        "s_nop 0\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA1], %[o1], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB1], %[o1], %[cB]\n\t"
+        "s_nop 0\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA2], %[o2], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB2], %[o2], %[cB]\n\t"
+        "s_nop 0\n\t"
+        "v_subb_co_u32_e64 %[j], %[cA], %[mA3], %[o3], %[cA]\n\t"
+        "v_subb_co_u32_e64 %[j], %[cB], %[mB3], %[o3], %[cB]\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %[rA], %[x], 0, %[rA], %[cA]\n\t"
+        "v_addc_co_u32_e64 %[rB], %[x], 0, %[rB], %[cB]\n\t"
+        : [rA] "+v"(rA), [rB] "+v"(rB), [j] "=&v"(j), [x] "=&s"(x), [cA] "=&s"(cA), [cB] "=&s"(cB)
+        : [o0] "v"(o[0]), [o1] "v"(o[1]), [o2] "v"(o[2]), [o3] "v"(o[3]), [mA0] "v"(mA[0]), [mA1] "v"(mA[1]), [mA2] "v"(mA[2]), [mA3] "v"(mA[3]), [mB0] "v"(mB[0]), [mB1] "v"(mB[1]), [mB2] "v"(mB[2]), [mB3] "v"(mB[3]), [tA] "s"(tA), [tB] "s"(tB));
+}
+// N rows mine[0 .. N) against one other row: blocks of three, then two, then the single chain
+template <int W, int N, bool SHARED, typename MineAt, typename TieAt, typename RankAt>
+__device__ __forceinline__ void kb_rank_rows(const uint32_t (&o)[W], MineAt&& mine_at, TieAt&& tie_at, RankAt&& rank_at,
+                                             uint32_t& w) {
+  unrolled_while<0, (N + 2) / 3>([&](auto gc) {
+    constexpr int a = 3 * decltype(gc)::value;
+    if constexpr (a + 3 <= N) {
+      kb_rank3<W, SHARED>(o, mine_at(std::integral_constant<int, a>{}), mine_at(std::integral_constant<int, a + 1>{}),
+                          mine_at(std::integral_constant<int, a + 2>{}), tie_at(std::integral_constant<int, a>{}),
+                          tie_at(std::integral_constant<int, a + 1>{}), tie_at(std::integral_constant<int, a + 2>{}),
+                          rank_at(std::integral_constant<int, a>{}), rank_at(std::integral_constant<int, a + 1>{}),
+                          rank_at(std::integral_constant<int, a + 2>{}), w);
+    } else if constexpr (a + 2 == N) {
+      kb_rank2<W, SHARED>(o, mine_at(std::integral_constant<int, a>{}), mine_at(std::integral_constant<int, a + 1>{}),
+                          tie_at(std::integral_constant<int, a>{}), tie_at(std::integral_constant<int, a + 1>{}),
+                          rank_at(std::integral_constant<int, a>{}), rank_at(std::integral_constant<int, a + 1>{}), w);
+    } else if constexpr (a + 1 == N) {
+      const LaneMask c = key_other_first<W>(mine_at(std::integral_constant<int, a>{}), o, tie_at(std::integral_constant<int, a>{}));
+      kb_count(rank_at(std::integral_constant<int, a>{}), c);
+      if constexpr (SHARED) kb_count(w, c);
+    }
+    return true;
+  });
+}
+
 
 // ---- Zeillinger's pair test for the kernels that split a game over lanes (hk_duo_kernel.h, hk_quadroll_kernel.h) ------
 // The best pair so far as ONE comparable key: hi = the bits of L (a non-negative finite float: its bit pattern orders
@@ -596,9 +827,10 @@ struct ZeilBest {
 // dimension 4 two rounds of a sorting network leave minimum, maximum and the two middle values, #max + #min = 2 + the
 // middle values' matches.  "better" is the borrow of key - best over the two words, selecting directly.
 // OK = false: the caller has no pairs to leave out (`ok` is not looked at).
-template <int D, bool KEEP, bool OK = true>
-__device__ __forceinline__ void zeil_pair(ZeilBest<D>& best, const float* mine, const float* other, bool ok, int idx) {
-  float v[D];
+// the pair's key: hi = the pattern of L (all ones: the pair does not count), lo = S << 16 | idx
+template <int D, bool OK>
+__device__ __forceinline__ void zeil_key(const float* mine, const float* other, bool ok, int idx, uint32_t& khi,
+                                         uint32_t& klo, float (&v)[D]) {
 #pragma unroll
   for (int k = 0; k < D; ++k) v[k] = mine[k] - other[k];
   float mx, mn;
@@ -631,7 +863,15 @@ __device__ __forceinline__ void zeil_pair(ZeilBest<D>& best, const float* mine, 
   const float L = mx - mn;
   const bool close = fabsf(L) <= 1e-8f + 1e-5f * fabsf(mn);  // jnp.isclose(max, min)
   const bool out = OK ? (close | !ok) : close;
-  const uint32_t khi = out ? 0xFFFFFFFFu : __float_as_uint(L), klo = (cnt << 16) | (uint32_t)idx;
+  khi = out ? 0xFFFFFFFFu : __float_as_uint(L);
+  klo = (cnt << 16) | (uint32_t)idx;
+}
+
+template <int D, bool KEEP, bool OK = true>
+__device__ __forceinline__ void zeil_pair(ZeilBest<D>& best, const float* mine, const float* other, bool ok, int idx) {
+  float v[D];
+  uint32_t khi, klo;
+  zeil_key<D, OK>(mine, other, ok, idx, khi, klo, v);
   const LaneMask better = kb_subb(khi, best.hi, kb_subb(klo, best.lo, 0ull));  // best > key
   best.hi = kb_select(best.hi, khi, better);
   best.lo = kb_select(best.lo, klo, better);
@@ -641,25 +881,81 @@ __device__ __forceinline__ void zeil_pair(ZeilBest<D>& best, const float* mine, 
   }
 }
 
-// before the best so far travels to another lane through DPP
-template <int D, bool KEEP>
-__device__ __forceinline__ void zeil_dpp_safe(ZeilBest<D>& best) {
-  kb_dpp_safe(best.hi);
-  kb_dpp_safe(best.lo);
+// the same with the update as plain compares and selects (the two-lane kernel's unrolled DPP variant: it keeps the
+// difference too, and there the compiler's own sequence measured ahead of the chain: 37 against 42 us per episode)
+template <int D, bool KEEP, bool OK = true>
+__device__ __forceinline__ void zeil_pair_cmp(ZeilBest<D>& best, const float* mine, const float* other, bool ok, int idx) {
+  float v[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) v[k] = mine[k] - other[k];
+  float mx, mn;
+  uint32_t cnt;
+  if constexpr (D == 3) {
+    mx = __builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]);
+    mn = __builtin_fminf(__builtin_fminf(v[0], v[1]), v[2]);
+    const float md = __builtin_amdgcn_fmed3f(v[0], v[1], v[2]);
+    cnt = 2u + (uint32_t)(md == mx) + (uint32_t)(md == mn);
+  } else {
+    mx = v[0];
+    mn = v[0];
+#pragma unroll
+    for (int k = 1; k < D; ++k) {
+      mx = __builtin_fmaxf(mx, v[k]);
+      mn = __builtin_fminf(mn, v[k]);
+    }
+    cnt = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) cnt += (uint32_t)(v[k] == mx) + (uint32_t)(v[k] == mn);
+  }
+  const float L = mx - mn;
+  const bool close = fabsf(L) <= 1e-8f + 1e-5f * fabsf(mn);  // jnp.isclose(max, min)
+  // (every term bitwise: with && / || the compiler made each one a branch on the exec mask)
+  const bool valid = (OK ? ok : true) & (mine[0] < INFINITY) & (other[0] < INFINITY) & !close;
+  const uint32_t khi = __float_as_uint(L), klo = (cnt << 16) | (uint32_t)idx;
+  const bool better = valid & ((khi < best.hi) | ((khi == best.hi) & (klo < best.lo)));
+  best.hi = better ? khi : best.hi;
+  best.lo = better ? klo : best.lo;
   if constexpr (KEEP) {
 #pragma unroll
-    for (int k = 0; k < D; ++k) kb_dpp_safe(best.bd[k]);
+    for (int k = 0; k < D; ++k) best.bd[k] = better ? v[k] : best.bd[k];
   }
 }
 
+// two pairs, each against a best of its own: the two compare-and-select sequences interleaved in one block, so that every
+// instruction reads a borrow written two instructions (or one and an s_nop) earlier -- no wait per instruction
+template <int D>
+__device__ __forceinline__ void zeil_pair2(ZeilBest<D>& ba, ZeilBest<D>& bb, const float* mine_a, const float* other_a,
+                                           int idx_a, const float* mine_b, const float* other_b, int idx_b) {
+  float va[D], vb[D];
+  uint32_t ha, la, hb, lb, j;
+  LaneMask ca, cb;
+  zeil_key<D, false>(mine_a, other_a, true, idx_a, ha, la, va);
+  zeil_key<D, false>(mine_b, other_b, true, idx_b, hb, lb, vb);
+  asm("v_sub_co_u32_e64 %[j], %[ca], %[la], %[bal]\n\t"
+      "v_sub_co_u32_e64 %[j], %[cb], %[lb], %[bbl]\n\t"
+      "s_nop 0\n\t"
+      "v_subb_co_u32_e64 %[j], %[ca], %[ha], %[bah], %[ca]\n\t"
+      "v_subb_co_u32_e64 %[j], %[cb], %[hb], %[bbh], %[cb]\n\t"
+      "s_nop 0\n\t"
+      "v_cndmask_b32_e64 %[bah], %[bah], %[ha], %[ca]\n\t"
+      "v_cndmask_b32_e64 %[bal], %[bal], %[la], %[ca]\n\t"
+      "v_cndmask_b32_e64 %[bbh], %[bbh], %[hb], %[cb]\n\t"
+      "v_cndmask_b32_e64 %[bbl], %[bbl], %[lb], %[cb]"
+      : [bah] "+v"(ba.hi), [bal] "+v"(ba.lo), [bbh] "+v"(bb.hi), [bbl] "+v"(bb.lo), [j] "=&v"(j), [ca] "=&s"(ca),
+        [cb] "=&s"(cb)
+      : [ha] "v"(ha), [la] "v"(la), [hb] "v"(hb), [lb] "v"(lb));
+}
+
+// (plain compares and selects: once per call, and its results travel through DPP next -- instructions the compiler
+// spaces itself)
 template <int D, bool KEEP>
 __device__ __forceinline__ void zeil_merge(ZeilBest<D>& best, const ZeilBest<D>& o) {
-  const LaneMask take = kb_subb(o.hi, best.hi, kb_subb(o.lo, best.lo, 0ull));
-  best.hi = kb_select(best.hi, o.hi, take);
-  best.lo = kb_select(best.lo, o.lo, take);
+  const bool take = (o.hi < best.hi) | ((o.hi == best.hi) & (o.lo < best.lo));
+  best.hi = take ? o.hi : best.hi;
+  best.lo = take ? o.lo : best.lo;
   if constexpr (KEEP) {
 #pragma unroll
-    for (int k = 0; k < D; ++k) best.bd[k] = kb_select(best.bd[k], o.bd[k], take);
+    for (int k = 0; k < D; ++k) best.bd[k] = take ? o.bd[k] : best.bd[k];
   }
 }
 

@@ -595,44 +595,38 @@ __device__ __forceinline__ void qd_ranks_stable_t(const float (&q)[R * D], int j
   uint32_t ownlost[NB];
 #pragma unroll
   for (int s = 0; s < NB; ++s) ownlost[s] = 0u;
-#pragma unroll
-  for (int a = 0; a + 1 < NB; ++a)
-#pragma unroll
-    for (int b = a + 1; b < NB; ++b) {  // own slots: a is the earlier row, b first iff its key is strictly greater
-      const LaneMask c = key_other_first<W>(kw[a], kw[b], none);
-      kb_count(rk[a], c);
-      kb_count(ownlost[b], c);
-    }
-#pragma unroll
-  for (int b = 1; b < NB; ++b) rk[b] += (uint32_t)b - ownlost[b];  // (my holes a < b lose against a live b)
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
+  auto mine_at = [&](auto ac) -> const uint32_t(&)[W] { return kw[decltype(ac)::value]; };
+  auto rank_at = [&](auto ac) -> uint32_t& { return rk[decltype(ac)::value]; };
+  auto no_tie = [&](auto) { return none; };
+  // (the chains run in blocks of three rows of mine against one other row: kb_rank_rows)
+  unrolled_while<0, NB>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    // own slots a < b: a is the earlier row, b first iff its key is strictly greater
+    kb_rank_rows<W, b, true>(kw[b], mine_at, no_tie, rank_at, ownlost[b]);
     uint32_t p1[W], p2[W];
 #pragma unroll
     for (int i = 0; i < W; ++i) {
       p1[i] = (uint32_t)qperm_i<kQuadUp1>((int)kw[b][i]);
       p2[i] = (uint32_t)qperm_i<kQuadUp2>((int)kw[b][i]);
     }
-#pragma unroll
-    for (int a = 0; a < NB; ++a) {
-      {  // the lane one up: all pairs; on equal keys its row is the earlier one iff b < a, or b == a on lane 3
-        const LaneMask c = key_other_first<W>(kw[a], p1, b < a ? all : (b == a ? late1 : none));
-        kb_count(rk[a], c);
-        kb_count(won1[b], c);
-      }
-      if (a < b) {  // the lane two up: pairs a < b (it does the mirror image); equal keys: my row is the earlier one
-        const LaneMask c = key_other_first<W>(kw[a], p2, none);
-        kb_count(rk[a], c);
-        kb_count(won2[b], c);
-      } else if (a == b) {  // the diagonal is counted ONCE, by the lower lane of the two
-        const LaneMask c = key_other_first<W>(kw[a], p2, none);
-        LaneMask live_a;
-        asm("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(live_a) : "v"(kw[a][W - 1]));
-        kb_count(rk[a], c & early2);
-        kb_count(diag2[b], ~c & early2 & live_a);
-      }
+    // the lane one up: all pairs; on equal keys its row is the earlier one iff b < a, or b == a on lane 3
+    kb_rank_rows<W, NB, true>(p1, mine_at, [&](auto ac) {
+      constexpr int a = decltype(ac)::value;
+      return b < a ? all : (b == a ? late1 : none);
+    }, rank_at, won1[b]);
+    // the lane two up: pairs a < b (it does the mirror image); equal keys: my row is the earlier one
+    kb_rank_rows<W, b, true>(p2, mine_at, no_tie, rank_at, won2[b]);
+    {  // ... and the diagonal, counted ONCE, by the lower lane of the two
+      const LaneMask c = key_other_first<W>(kw[b], p2, none);
+      LaneMask live_b;
+      asm("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(live_b) : "v"(kw[b][W - 1]));
+      kb_count(rk[b], c & early2);
+      kb_count(diag2[b], ~c & early2 & live_b);
     }
-  }
+    return true;
+  });
+#pragma unroll
+  for (int b = 1; b < NB; ++b) rk[b] += (uint32_t)b - ownlost[b];  // (my holes a < b lose against a live b)
 #pragma unroll
   for (int s = 0; s < R; ++s) rank[s] = 0;
 #pragma unroll
@@ -689,11 +683,10 @@ __device__ __forceinline__ void qd_ranks_lds_t(const float (&q)[R * D], float* c
       for (int i = 0; i < W; ++i) pj[i] = src[i];
     }
     const int dj = row - j;  // (row < 4 s + j  <=>  dj < 4 s)
-#pragma unroll
-    for (int s = 0; s < NB; ++s) {
-      const LaneMask tie = TIES ? __ballot(dj < kQuad * s) : 0ull;
-      kb_count(rk[s], key_other_first<W>(kw[s], pj, tie));
-    }
+    uint32_t unused = 0u;
+    kb_rank_rows<W, NB, false>(pj, [&](auto sc) -> const uint32_t(&)[W] { return kw[decltype(sc)::value]; },
+                               [&](auto sc) { return TIES ? __ballot(dj < kQuad * decltype(sc)::value) : 0ull; },
+                               [&](auto sc) -> uint32_t& { return rk[decltype(sc)::value]; }, unused);
   }
 #pragma unroll
   for (int s = 0; s < R; ++s) rank[s] = 0;

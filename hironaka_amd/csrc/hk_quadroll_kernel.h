@@ -363,9 +363,17 @@ __device__ __forceinline__ int qr_zeillinger(const float (&q)[R * D], float* cmi
   };
 #pragma nounroll
   for (int t = 0; t + 1 < passes; ++t) {  // (all but the last pass: every position exists)
-    pair(best, i, jj, std::false_type{}, true);
+    float pa[D], qa[D], pb[D], qb[D];
+    const int ia = i, ja = jj;
     advance();
-    pair(second, i, jj, std::false_type{}, true);
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      pa[k] = cmine[ia * CW + k];
+      qa[k] = cmine[ja * CW + k];
+      pb[k] = cmine[i * CW + k];
+      qb[k] = cmine[jj * CW + k];
+    }
+    zeil_pair2<D>(best, second, pa, qa, 64 * ia + ja, pb, qb, 64 * i + jj);
     advance();
   }
   if (passes > 0) {
@@ -378,11 +386,9 @@ __device__ __forceinline__ int qr_zeillinger(const float (&q)[R * D], float* cmi
   zeil_merge<D, false>(best, second);
   {
     ZeilBest<D> o;
-    zeil_dpp_safe<D, false>(best);
     o.hi = (uint32_t)qperm_i<kQuadUp1>((int)best.hi);
     o.lo = (uint32_t)qperm_i<kQuadUp1>((int)best.lo);
     zeil_merge<D, false>(best, o);
-    zeil_dpp_safe<D, false>(best);
     o.hi = (uint32_t)qperm_i<kQuadUp2>((int)best.hi);
     o.lo = (uint32_t)qperm_i<kQuadUp2>((int)best.lo);
     zeil_merge<D, false>(best, o);
