@@ -132,3 +132,28 @@ def test_graft_entry_build_runs():
     G.build()
     from hironaka_amd import _abi, _lib
     assert _lib.lib().hk_abi_version() == _abi.HK_ABI_VERSION
+
+
+def test_inline_asm_keeps_the_scalar_register_hazard_distance(tmp_path):
+    """gfx950 wants two wait states between a vector instruction that writes a scalar register pair and a vector
+    instruction that reads it; the compiler's hazard recogniser does not look into inline asm, and the borrow-chain
+    blocks (hk_fast_rows.h: kb_rank3 / kb_rank2 / zeil_pair2, the single chain's s_nop) provide the distance
+    themselves.  A device listing of the kernels that use them is scanned for the smallest distance."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import check_sgpr_hazards
+    src = os.path.join(ROOT, "hironaka_amd", "csrc")
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+             "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero", "-mllvm",
+             "-amdgpu-kernarg-preload-count=8", "-S", "--cuda-device-only"]
+    jobs = []
+    for tu, m, d in (("hk_quad_spec.hip", 20, 3), ("hk_quadroll_spec.hip", 20, 4)):
+        out = str(tmp_path / f"{tu}_{m}_{d}.s")
+        jobs.append((out, subprocess.Popen(["/opt/rocm/bin/hipcc", *flags, f"-DHK_SPEC_M={m}", f"-DHK_SPEC_D={d}",
+                                            os.path.join(src, tu), "-o", out], stderr=subprocess.DEVNULL)))
+    for out, proc in jobs:
+        assert proc.wait() == 0
+        violations, distances = check_sgpr_hazards.scan(out)
+        assert violations == 0, distances
+        assert distances.get("v_subb_co_u32_e64", 2) >= 2 and distances.get("v_addc_co_u32_e64", 2) >= 2
