@@ -775,14 +775,16 @@ int hk_zeillinger(const void* points, int64_t stride, int32_t* class_out, int ba
     Params fast = prm;
     fast.mode = kModeStep;
     fast.pad = -1.0;
-    if (fast_supported(fast, dtype)) return launch_fast(fast, (hipStream_t)stream);
-    // the large games on four lanes per game (hk_quadroll_kernel.h: the rollout kernel's prologue + pair loop): the JAX
-    // variant over contiguous 16-B aligned records
-    if (dtype == HK_F32 && max_points > 32 && (flags & HK_SEM_MASK) == HK_SEM_JAX && !(flags & HK_FLAG_FORCE_TEAM) &&
+    // four lanes per game (hk_quadroll_kernel.h: the rollout kernel's prologue + its balanced pair loop) wherever that
+    // kernel exists: the JAX variant over contiguous 16-B aligned records ((20,3) x 65 536: 21.4 us on one lane per
+    // game, (20,4): 37.4)
+    if (dtype == HK_F32 && (flags & HK_SEM_MASK) == HK_SEM_JAX &&
+        !(flags & (HK_FLAG_FORCE_TEAM | HK_FLAG_FORCE_ONE_LANE | HK_FLAG_FORCE_TWO_LANES)) &&
         stride == (int64_t)max_points * dim && aligned(points, 16)) {
       const int qs = launch_quadzeil(prm, (hipStream_t)stream);
       if (qs != HK_ERR_UNSUPPORTED) return qs;
     }
+    if (fast_supported(fast, dtype)) return launch_fast(fast, (hipStream_t)stream);
     if (team_supported(fast, dtype)) {
       const int ts = launch_team(fast, (hipStream_t)stream);
       if (ts != HK_ERR_UNSUPPORTED) return ts;
