@@ -1009,6 +1009,57 @@ def test_baseline_sizes(b, m, d):
     assert ((gl >= 0).sum() == dc[-1])
 
 
+@pytest.mark.parametrize("b,m,d", [(65536, 20, 3), (262144, 50, 4)])
+def test_baseline_sizes_other_operators(b, m, d):
+    """The state-reading operators and the other rollout configurations at BASELINE.json's sizes: oracle slices (first
+    and last 1 024 games, the policy streams keyed by the global index) and size-independent properties over the whole
+    batch -- the sorted features are sorted and idempotent, Zeillinger's class is a legal subset, a list-semantics
+    rollout leaves a compacted, descending state with the same games finished as the JAX-semantics one."""
+    P = ops.generate_points(b, m, d, 20, seed=7)
+    D = ops.generate_points(b, m, d, 20, seed=8, newton=False, reposition=False)
+    n_cls = 2 ** d - d - 1
+    slices = (slice(0, 1024), slice(b - 1024, b))
+    for pts in (P, D):
+        f = ops.get_features(pts)
+        ft = ops.get_features_torch(pts)
+        z = ops.zeillinger(pts)
+        for sl in slices:
+            hp = host(pts[sl])
+            assert np.array_equal(host(f[sl]), CO.get_features(hp))
+            assert np.array_equal(host(ft[sl]), CO.get_features_torch(hp))
+            assert np.array_equal(host(z[sl]), CO.zeillinger(hp))
+        assert int(z.min()) >= 0 and int(z.max()) < n_cls
+        f3 = f.reshape(b, m, d)
+        assert torch.equal(ops.get_features(f3), f)                       # sorted + rescaled once is a fixed point
+        key = f3[:, :, d - 1]
+        assert bool((key[:, :-1] >= key[:, 1:]).all())                    # last coordinate (primary key) descending
+        assert bool((ft[:, :-1, 0] >= ft[:, 1:, 0]).all())                # coordinate 0 descending, padding last
+        assert torch.equal(ops.get_num_points(ft), ops.get_num_points(pts))
+    g = torch.Generator(device="cuda").manual_seed(1)
+    cls = torch.randint(0, n_cls, (b,), device="cuda", generator=g, dtype=torch.int32)
+    ax = torch.randint(0, d, (b,), device="cuda", generator=g, dtype=torch.int32)
+    dense_next = ops.step(D, cls, ax, stages=7)["points"]                 # (50,4): the packed-row test
+    for sl in slices:
+        assert np.array_equal(host(dense_next[sl]), CO.step(host(D[sl]), host(cls[sl]), host(ax[sl]), stages=7)["points"])
+    assert torch.equal(ops.get_newton_polytope(dense_next), dense_next)
+    fl_o, fl_p = CO.flags_of(sem="list", noop_if_invalid=True), ops.make_flags("list", noop_if_invalid=True)
+    L = P.clone()
+    rl = ops.rollout(L, 20, 5, flags=fl_p, agent_policy=A.HK_AGENT_RANDOM_LEGAL, record=("game_length",))
+    Zs = P.clone()
+    rz = ops.rollout(Zs, 20, 5, host_policy=A.HK_HOST_ZEILLINGER, record=("game_length",))
+    for sl in slices:
+        want_p, want = CO.rollout(host(P[sl]), 20, 5, game_offset=sl.start, flags=fl_o, agent_policy=A.HK_AGENT_RANDOM_LEGAL,
+                                  record=False)
+        assert np.array_equal(host(L[sl]), want_p) and np.array_equal(host(rl["game_length"][sl]), want["game_length"])
+        want_p, want = CO.rollout(host(P[sl]), 20, 5, game_offset=sl.start, host_policy=A.HK_HOST_ZEILLINGER, record=False)
+        assert np.array_equal(host(Zs[sl]), want_p) and np.array_equal(host(rz["game_length"][sl]), want["game_length"])
+    live = L[:, :, 0] >= 0
+    assert bool((live[:, :-1] | ~live[:, 1:]).all())                     # compacted: no live row behind a padding row
+    both = live[:, :-1] & live[:, 1:]
+    assert bool((L[:, :-1, 0][both] >= L[:, 1:, 0][both]).all())           # coordinate 0 descending among the live rows
+    assert int(rl["done_count"][-1]) == int(ops.get_dones(L).sum())
+
+
 # ------------------------------------------------------------------------------------------
 # error behaviour at the boundary
 # ------------------------------------------------------------------------------------------
