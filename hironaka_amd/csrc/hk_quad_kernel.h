@@ -734,21 +734,27 @@ struct QgPackedSeg {
   // slot: the four rows' verdicts on a slot meet in scalar lane masks and are folded into the slot's counter at once
   // (one vector instruction per slot and segment; a lane mask per slot kept over the whole level overflows the scalar
   // registers: 2 000 spills in the build that tried).
+  // The test itself: row <= slot in every field  <=>  sum |slot_k - row_k| + sum row_k == sum slot_k (v_sad_u8 with the
+  // row's field sum as its addend, one compare: two instructions where the guard-bit subtraction takes three; the
+  // row's sum is one v_sad_u8 per row, the slot's one per slot).
   static __device__ __forceinline__ void run(const uint32_t (&w2)[NB2], const uint32_t (&g2)[NB2], uint32_t (&cnt)[NB2],
                                              const uint32_t* sv, int np1, int rows, int j, vu4 cur) {
     constexpr int r0 = kQuad * (C - 1);
     if (rows <= r0) return;  // (wave-uniform)
     vu4 nxt = cur;
     if constexpr (C < NB2) nxt = *reinterpret_cast<const vu4*>(sv + kQuad * C);
-    uint32_t c[kQuad];
+    uint32_t c[kQuad], cs[kQuad];
 #pragma unroll
-    for (int rr = 0; rr < kQuad; ++rr) c[rr] = (r0 + rr < np1) ? cur[rr] : kPackHole;  // (past np1: holes, dominating nothing)
+    for (int rr = 0; rr < kQuad; ++rr) {
+      c[rr] = (r0 + rr < np1) ? cur[rr] : kPackHole;  // (past np1: holes, dominating nothing)
+      cs[rr] = __builtin_amdgcn_sad_u8(c[rr], 0u, 0u);
+    }
 #pragma unroll
     for (int s = 0; s < NB2; ++s) {
       bool hit = false;
 #pragma unroll
       for (int rr = 0; rr < kQuad; ++rr) {
-        const bool dom = ((g2[s] - c[rr]) & kPackGuard) == kPackGuard;  // row <= my slot s, coordinate by coordinate
+        const bool dom = __builtin_amdgcn_sad_u8(w2[s], c[rr], cs[rr]) == g2[s];  // row <= my slot s, coordinate by coordinate
         if (s > C - 1) hit |= dom;                                      // my slot is the later row: equal rows count
         else if (s < C - 1) hit |= dom & (w2[s] != c[rr]);              // ... the earlier row: different rows only
         else hit |= dom & ((w2[s] != c[rr]) | (rr < j));                // ... decided by the ranks r0 + rr and r0 + j
@@ -768,7 +774,7 @@ __device__ __forceinline__ void qg_packed_level1(const uint32_t* sv, uint8_t* vd
     const int r = kQuad * s + j;
     const uint32_t v = sv[r < rows ? r : 0];
     w2[s] = (r < np1) ? v : kPackHole;
-    g2[s] = w2[s] | kPackGuard;
+    g2[s] = __builtin_amdgcn_sad_u8(w2[s], 0u, 0u);  // (the slot's field sum)
     cnt[s] = 0u;
   }
   QgPackedSeg<NB2, 1>::run(w2, g2, cnt, sv, np1, rows, j, first);  // (rows: wave-uniform, >= every game's np1)
@@ -795,13 +801,15 @@ __device__ __forceinline__ void qg_newton_on_packed(float (&q)[R * D], uint32_t 
     }
     const uint32_t c0 = bw, c1 = (uint32_t)qperm_i<kQuadUp1>((int)bw), c2 = (uint32_t)qperm_i<kQuadUp2>((int)bw),
                    c3 = (uint32_t)qperm_i<kQuadUp3>((int)bw);
+    const uint32_t s0 = __builtin_amdgcn_sad_u8(c0, 0u, 0u), s1 = __builtin_amdgcn_sad_u8(c1, 0u, 0u),
+                   s2 = __builtin_amdgcn_sad_u8(c2, 0u, 0u), s3 = __builtin_amdgcn_sad_u8(c3, 0u, 0u);
 #pragma unroll
     for (int s = 0; s < NB; ++s) {
-      const uint32_t g = w[s] | kPackGuard;
-      const bool r0 = (((g - c0) & kPackGuard) == kPackGuard) & (w[s] != c0);
-      const bool r1 = (((g - c1) & kPackGuard) == kPackGuard) & (w[s] != c1);
-      const bool r2 = (((g - c2) & kPackGuard) == kPackGuard) & (w[s] != c2);
-      const bool r3 = (((g - c3) & kPackGuard) == kPackGuard) & (w[s] != c3);
+      const uint32_t g = __builtin_amdgcn_sad_u8(w[s], 0u, 0u);  // (champion <= slot in every field: see QgPackedSeg)
+      const bool r0 = (__builtin_amdgcn_sad_u8(w[s], c0, s0) == g) & (w[s] != c0);
+      const bool r1 = (__builtin_amdgcn_sad_u8(w[s], c1, s1) == g) & (w[s] != c1);
+      const bool r2 = (__builtin_amdgcn_sad_u8(w[s], c2, s2) == g) & (w[s] != c2);
+      const bool r3 = (__builtin_amdgcn_sad_u8(w[s], c3, s3) == g) & (w[s] != c3);
       w[s] = (r0 | r1 | r2 | r3) ? kPackHole : w[s];
     }
   }
