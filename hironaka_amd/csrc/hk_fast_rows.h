@@ -575,22 +575,6 @@ __device__ __forceinline__ uint32_t kb_select(uint32_t keep, uint32_t take, Lane
 __device__ __forceinline__ float kb_select(float keep, float take, LaneMask c) {
   return __uint_as_float(kb_select(__float_as_uint(keep), __float_as_uint(take), c));
 }
-// a row of D floats becomes `take` on the lanes of c (one wait for the block)
-template <int D>
-__device__ __forceinline__ void kb_select_row(float* row, float take, LaneMask c) {
-  static_assert(D >= 2 && D <= 4, "rows of two to four coordinates");
-  if constexpr (D == 4)
-    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %0, %4, %5\n\tv_cndmask_b32_e64 %1, %1, %4, %5\n\t"
-        "v_cndmask_b32_e64 %2, %2, %4, %5\n\tv_cndmask_b32_e64 %3, %3, %4, %5"
-        : "+v"(row[0]), "+v"(row[1]), "+v"(row[2]), "+v"(row[3]) : "v"(take), "s"(c));
-  else if constexpr (D == 3)
-    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %0, %3, %4\n\tv_cndmask_b32_e64 %1, %1, %3, %4\n\t"
-        "v_cndmask_b32_e64 %2, %2, %3, %4"
-        : "+v"(row[0]), "+v"(row[1]), "+v"(row[2]) : "v"(take), "s"(c));
-  else
-    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %0, %2, %3\n\tv_cndmask_b32_e64 %1, %1, %2, %3"
-        : "+v"(row[0]), "+v"(row[1]) : "v"(take), "s"(c));
-}
 // Three (two) chains against the SAME other row, interleaved link by link, and their counts, as one block: a link reads
 // the borrow its chain wrote three (two + s_nop 0) instructions earlier, a count the borrow of a chain that ended two
 // instructions before it -- the two wait states are in the order of the instructions, no s_nop per instruction.

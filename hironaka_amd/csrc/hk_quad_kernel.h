@@ -329,107 +329,6 @@ __device__ __forceinline__ void qd_newton(float (&q)[R * D], int j) {
   }
 }
 
-// ---- the DPP test on PACKED rows (the rollouts' first steps: several slots per lane, small integral coordinates) -------
-// A row of up to four integral coordinates <= 254 is one word of byte fields (v_cvt_pk_u8_f32 saturates: a hole, +inf
-// everywhere, is 255 in every field -- above every live row, below none), and
-//     a <= b in every field  <=>  sum |b_k - a_k| + sum a_k == sum b_k          (v_sad_u8 + one compare)
-// so a pair costs four vector instructions where the float test takes twelve, and a partner's row travels as two
-// words (row, field sum).  The verdicts are lane masks in scalar registers: or / andn2 there, and a nibble rotation
-// instead of the DPP trip back to the row's owner.  The caller knows that the rows are integral (fract() of every
-// coordinate once per episode, then only shifts and repositions); the range is checked here.
-// w[s], sum[s]: the packed row of slot s and its field sum; false (wave-uniform) if a live coordinate exceeds 254
-// fract() of every coordinate: all zero <=> the rows are integral (a hole: fract(+inf) is NaN or 0 -- the maximum skips it)
-template <int R, int D>
-__device__ __forceinline__ float qd_fract_max(const float (&q)[R * D], int slots, float acc) {
-  unrolled_while<0, R>([&](auto sc) {
-    constexpr int s = decltype(sc)::value;
-    if (s >= slots) return false;
-#pragma unroll
-    for (int k = 0; k < D; ++k) acc = __builtin_fmaxf(acc, __builtin_amdgcn_fractf(q[s * D + k]));
-    return true;
-  });
-  return acc;
-}
-template <int R, int D, int NB>
-__device__ __forceinline__ bool qd_pack_bytes(const float (&q)[R * D], uint32_t (&w)[NB], uint32_t (&sum)[NB]) {
-  static_assert(D <= 4, "four fields");
-  uint32_t bad = 0u;
-#pragma unroll
-  for (int s = 0; s < NB; ++s) {
-    uint32_t raw = 0u;
-#pragma unroll
-    for (int k = 0; k < D; ++k) raw = __builtin_amdgcn_cvt_pk_u8_f32(q[s * D + k], k, raw);
-    if constexpr (D < 4) raw |= (q[s * D] < INFINITY) ? 0u : (0xFFFFFFFFu << (8 * D));  // (a hole: 255 in the unused fields too)
-    // a field of 255 in a live row: the coordinate was 255 or more (~raw has a zero byte: (v - 0x01..) & ~v & 0x80..)
-    const uint32_t inv = ~raw;
-    const uint32_t sat = (inv - 0x01010101u) & raw & 0x80808080u;
-    bad |= (q[s * D] < INFINITY) ? sat : 0u;
-    w[s] = raw;
-    sum[s] = __builtin_amdgcn_sad_u8(raw, 0u, 0u);
-  }
-  return !__any(bad != 0u);
-}
-__device__ __forceinline__ LaneMask quad_rotl1(LaneMask m) {  // the verdicts of the lane one down / two up about my slot
-  return ((m << 1) & 0xEEEEEEEEEEEEEEEEull) | ((m >> 3) & 0x1111111111111111ull);
-}
-__device__ __forceinline__ LaneMask quad_rotl2(LaneMask m) {
-  return ((m << 2) & 0xCCCCCCCCCCCCCCCCull) | ((m >> 2) & 0x3333333333333333ull);
-}
-template <int R, int D, int NB>
-__device__ __forceinline__ void qd_newton_bytes(float (&q)[R * D], const uint32_t (&w)[NB], const uint32_t (&sum)[NB]) {
-  LaneMask rem[NB], r1[NB], r2[NB];
-#pragma unroll
-  for (int s = 0; s < NB; ++s) rem[s] = r1[s] = r2[s] = 0ull;
-  // a <= b in every field, as lane masks
-  auto le = [](uint32_t a, uint32_t sa, uint32_t b, uint32_t sb) { return __ballot(__builtin_amdgcn_sad_u8(a, b, sa) == sb); };
-#pragma unroll
-  for (int a = 0; a + 1 < NB; ++a)
-#pragma unroll
-    for (int b = a + 1; b < NB; ++b) {  // own slots: a is the earlier row
-      const LaneMask A = le(w[a], sum[a], w[b], sum[b]), B = le(w[b], sum[b], w[a], sum[a]);
-      rem[b] |= A;
-      rem[a] |= B & ~A;
-    }
-  const LaneMask mine1 = 0x7777777777777777ull, mine2 = 0x3333333333333333ull;  // on the diagonal: my row is the earlier
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const uint32_t p1 = (uint32_t)qperm_i<kQuadUp1>((int)w[b]), s1 = (uint32_t)qperm_i<kQuadUp1>((int)sum[b]);
-    const uint32_t p2 = (uint32_t)qperm_i<kQuadUp2>((int)w[b]), s2 = (uint32_t)qperm_i<kQuadUp2>((int)sum[b]);
-#pragma unroll
-    for (int a = 0; a < NB; ++a) {
-      {  // the lane one up: all pairs.  A: mine <= other (the other goes, if mine is the earlier row or they differ)
-        const LaneMask A = le(w[a], sum[a], p1, s1), B = le(p1, s1, w[a], sum[a]);
-        if (a < b) {
-          r1[b] |= A;
-          rem[a] |= B & ~A;
-        } else if (a > b) {
-          r1[b] |= A & ~B;
-          rem[a] |= B;
-        } else {
-          r1[b] |= A & (mine1 | ~B);
-          rem[a] |= B & (~mine1 | ~A);
-        }
-      }
-      if (a <= b) {  // the lane two up: pairs a < b (it does the mirror image) and the diagonal (both do)
-        const LaneMask A = le(w[a], sum[a], p2, s2), B = le(p2, s2, w[a], sum[a]);
-        if (a < b) {
-          r2[b] |= A;
-          rem[a] |= B & ~A;
-        } else {
-          r2[b] |= A & (mine2 | ~B);
-          rem[a] |= B & (~mine2 | ~A);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int s = 0; s < NB; ++s) {
-    // (q[] is next read by the row count and by the next step's shift -- compiler-generated selects on every coordinate --
-    // before any DPP instruction sees it)
-    kb_select_row<D>(&q[s * D], INFINITY, rem[s] | quad_rotl1(r1[s]) | quad_rotl2(r2[s]));
-  }
-}
-
 // The same test for MANY slots per lane (more than kQuadDppSlots: states that no Newton pass has thinned yet), as a
 // rolled loop over the game's rows through the compact image instead of 2 NB^2 unrolled pair tests: the quad parks
 // its rows at their ranks, then rows j = 4(c-1) .. 4c-1 (one broadcast read per j) meet the lane's slots 0 .. c-1,

@@ -101,29 +101,15 @@ __device__ __forceinline__ void qr_reposition_bin(float (&q)[R * D]) {
 }
 
 // one transition on slots [0, NB) of the four lanes with the policy's 0/1 subset `cmask`; returns the GAME's live rows
-// `packable` (wave-uniform, sticky): the rows are integral and so far every coordinate fitted a byte -- the levels of 3 to
-// kQrPackedSlots slots per lane then test packed rows (qd_newton_bytes); the first step that does not fit ends it
-constexpr int kQrPackedMin = 3, kQrPackedSlots = 6;
 template <int M, int CW, int R, int D, int NB>
 __device__ __forceinline__ int qr_stages(float (&q)[R * D], uint32_t cmask, int axis, int np, int j, unsigned flags,
-                                         unsigned stages, float* cmine, int smax, bool& packable) {
+                                         unsigned stages, float* cmine, int smax) {
   if (stages & HK_STAGE_SHIFT) b_shift_mask<R, D, NB>(q, cmask, axis, np, flags);
   if (stages & HK_STAGE_REPOSITION) qr_reposition_bin<R, D, NB>(q);
   if (stages & HK_STAGE_NEWTON) {
     if constexpr (NB > kQuadDppSlots) {
       const int slots_end = kQuad * smax < M ? kQuad * smax : M;
       qd_newton_lds<M, CW, R, D, NB, true>(q, cmine, j, slots_end);
-    } else if constexpr (NB >= kQrPackedMin && NB <= kQrPackedSlots && D <= 4) {
-      bool done = false;
-      if (packable) {
-        uint32_t w[NB], sum[NB];
-        packable = qd_pack_bytes<R, D, NB>(q, w, sum);
-        if (packable) {
-          qd_newton_bytes<R, D, NB>(q, w, sum);
-          done = true;
-        }
-      }
-      if (!done) qd_newton<R, D, NB>(q, j);
     } else {
       qd_newton<R, D, NB>(q, j);
     }
@@ -697,8 +683,6 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
   }
   if (!active) np = 2;  // never finished, never counted
   int length = (np < 2) ? 0 : -1;
-  // integral rows stay integral under shifts and repositions (a rescale stage ends that): qd_newton_bytes
-  bool packable = !(stages & HK_STAGE_RESCALE) && smax >= kQrPackedMin && !__any(qd_fract_max<R, D>(q, smax, 0.0f) > 0.0f);
 
   // ---- the steps: a staircase of loops, one per bucket of slots per lane ---------------------------------------------
   const bool want_obs = REC && prm.obs_out != nullptr;
@@ -816,7 +800,7 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
         // (end_sort: the last step's rescale waits until the rows are ranked, at the publish)
         const unsigned st = (kEndSort && end_sort && t + 1 == nsteps) ? (stages & ~(unsigned)HK_STAGE_RESCALE) : stages;
         if constexpr (kEndSort) rescale_pending = end_sort && t + 1 == nsteps && (stages & HK_STAGE_RESCALE);
-        np = qr_stages<M, CW, R, D, NB>(q, cmask, axis, np, j, flags, st, cmine, smax, packable);
+        np = qr_stages<M, CW, R, D, NB>(q, cmask, axis, np, j, flags, st, cmine, smax);
         if (!active) np = 2;
         const bool done = np < 2;
         if (done && length < 0) length = t + 1;
