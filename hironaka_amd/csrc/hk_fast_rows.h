@@ -296,7 +296,8 @@ __device__ __forceinline__ void b_reposition(float (&q)[C * D], unsigned flags) 
       }
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-      const float sub = (mb[k] == 0x7F800000u) ? 0.0f : __uint_as_float(mb[k]);
+      // (no live row in the column: subtract the largest finite float -- +inf stays +inf; see hk_duo_kernel.h)
+      const float sub = __uint_as_float(mb[k] < 0x7F7FFFFFu ? mb[k] : 0x7F7FFFFFu);
 #pragma unroll
       for (int r = 0; r < NB; ++r) q[r * D + k] = q[r * D + k] - sub;
     }

@@ -94,7 +94,9 @@ __device__ __forceinline__ void qr_reposition_bin(float (&q)[R * D]) {
     mb[k] = o < mb[k] ? o : mb[k];
     o = (uint32_t)qperm_i<kQuadUp2>((int)mb[k]);
     mb[k] = o < mb[k] ? o : mb[k];
-    const float sub = (mb[k] == 0x7F800000u) ? 0.0f : __uint_as_float(mb[k]);
+    // (a column without live rows -- an empty game -- subtracts the largest finite float: +inf stays +inf, one
+    // v_min_u32 where the test for +inf took a compare and a select)
+    const float sub = __uint_as_float(mb[k] < 0x7F7FFFFFu ? mb[k] : 0x7F7FFFFFu);
 #pragma unroll
     for (int r = 0; r < NB; ++r) q[r * D + k] = q[r * D + k] - sub;
   }
