@@ -558,7 +558,8 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   __shared__ __align__(16) float lds[kDuoGames * G::S];
   __shared__ float cbuf[kDuoGames * D];  // slow path only
   // plain rollouts: the policy words of a window of steps (duo_policy_fill)
-  __shared__ __align__(16) uint8_t pol[(MODE == kModeRollout) ? 4 * kDuoPreBlocks * kDuoGames : 16];
+  // (one row more than the window: the step loop requests the NEXT step's byte while it works on this one)
+  __shared__ __align__(16) uint8_t pol[(MODE == kModeRollout) ? (4 * kDuoPreBlocks + 1) * kDuoGames : 16];
   const int lane = threadIdx.x;
   const int h = lane & 1, gi = lane >> 1;
   const int64_t g0 = (int64_t)blockIdx.x * kDuoGames;
@@ -788,6 +789,9 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
     // last step (exclusive) the window covers
     const uint32_t wend_abs = (pol_b0 + (uint32_t)kDuoPreBlocks) << 2;
     const int tw = (!ZEIL && wend_abs - step0 < (uint32_t)nsteps) ? (int)(wend_abs - step0) : nsteps;
+    // the action byte of step t, requested one step ahead: the LDS round trip (it opened every step: ds_read, wait)
+    // runs behind the previous step's arithmetic
+    uint32_t a_next = ZEIL ? 0u : pol[(int)(step0 + (uint32_t)t - (pol_b0 << 2)) * kDuoGames + gi];
     DuoLevels<CH>::run([&](auto nbc, auto loc) {
       constexpr int NB = decltype(nbc)::value, LO = decltype(loc)::value;
 #ifndef HK_NO_SETPRIO
@@ -819,7 +823,8 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
           duo_policy_words(gg, step0 + (uint32_t)t, seed, dcache, h, ra, rb);
           policy_from_words<D>(ra, rb, host_policy, agent_policy, cls, axis, mask, zc);
         } else {
-          const uint32_t a = pol[(int)(step0 + (uint32_t)t - (pol_b0 << 2)) * kDuoGames + gi];
+          const uint32_t a = a_next;
+          a_next = pol[(int)(step0 + (uint32_t)t + 1u - (pol_b0 << 2)) * kDuoGames + gi];  // (past the window: not used)
           mask = a & 31u;
           axis = (int)(a >> 5);
         }

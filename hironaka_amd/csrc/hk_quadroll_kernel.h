@@ -43,7 +43,8 @@ struct QuadRollGeom {
   static constexpr int kCompact = kQuadGames * M * CW;
   static constexpr int kRegion = Q::kImage > kCompact ? Q::kImage : kCompact;  // floats: image and compact image alias
   static constexpr int kTags = (kQuadGames * M + 15) / 16 * 16;                 // bytes
-  static constexpr int kActs = kQrSteps * kQuadGames;                          // bytes (>= the slow path's scratch)
+  static constexpr int kActs = (kQrSteps + 1) * kQuadGames;  // bytes (>= the slow path's scratch); one row more than the
+                                                              // window: the step loop requests the next step's byte ahead
   static constexpr int kWaveBytes = kRegion * 4 + kTags + kActs;
   static constexpr bool kBig = kWaveBytes > 12 * 1024;
   // waves per workgroup: four; one for the large games, whose 160 KB of LDS per CU then hold 11 waves (three waves
@@ -766,6 +767,8 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
     const uint32_t wleft = wstep0 + (uint32_t)kQrSteps - step0;  // steps (from 0) the window reaches
     const int tw = (!ZEIL && wleft < (uint32_t)nsteps) ? (int)wleft : nsteps;
     const uint8_t* arow = act + gi;
+    // the action byte of step t, requested one step ahead (the LDS round trip opened every step: hk_duo_kernel.h)
+    uint32_t a_next = ZEIL ? 0u : arow[(int)(step0 + (uint32_t)t - wstep0) * kQuadGames];
     QuadLevels<M, D, R>::run([&](auto nbc, auto loc) {
       constexpr int NB = decltype(nbc)::value, LO = decltype(loc)::value;
       // (no s_setprio by bucket here: with three or four waves per SIMD it starves the others -- measured 24.4 -> 26.5 us
@@ -781,7 +784,8 @@ __global__ __launch_bounds__(kWave * WPB, (QuadRollGeom<M, D>::kWavesPerSimd)) v
           policy_words(gg_game, step0 + (uint32_t)t, seed, zcache, D, ra, rb);
           policy_from_words<D>(ra, rb, host_policy, agent_policy, cls, axis, cmask, zc);
         } else {
-          const uint32_t a = arow[(int)(step0 + (uint32_t)t - wstep0) * kQuadGames];
+          const uint32_t a = a_next;
+          a_next = arow[(int)(step0 + (uint32_t)t + 1u - wstep0) * kQuadGames];  // (past the window: not used)
           cmask = a & 31u;
           axis = (int)(a >> 5);
         }
