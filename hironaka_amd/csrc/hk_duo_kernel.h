@@ -170,6 +170,37 @@ __device__ __forceinline__ uint32_t duo_scatter(const float (&q)[CH * D], float*
   return alive | (uint32_t)duo_other_i((int)alive);
 }
 
+// one pass over the lane's HALF of the game's image (rows h * ceil(M / 2) ...): bitmask of the fully available rows of
+// the whole game (the partner's half through DPP) + representability of the lane's half (the caller ANDs over the wave)
+template <int M, int D>
+__device__ __forceinline__ void duo_scan_half(const float* mine, float fill, int h, uint32_t& live, bool& ok) {
+  static_assert(M <= 32, "the game's mask is one word");
+  constexpr int C = (M + 1) / 2;
+  const int i0 = h * C;
+  const float* base = mine + i0 * D;
+  uint32_t mask = 0;
+  ok = true;
+  const uint32_t fill_bits = __float_as_uint(fill);
+#pragma unroll
+  for (int r = 0; r < C; ++r) {
+    // (M odd: the second lane's last row lies past the game -- its read stays inside the wave's image and is not counted)
+    const bool valid = (M % 2 == 0) || r + 1 < C || h == 0;
+    uint32_t hi = __float_as_uint(base[r * D]), lo = hi;
+#pragma unroll
+    for (int k = 1; k < D; ++k) {
+      const uint32_t u = __float_as_uint(base[r * D + k]);
+      hi = u > hi ? u : hi;
+      lo = u < lo ? u : lo;
+    }
+    const bool ge = hi < 0x7F800000u;
+    const bool fl = (lo == fill_bits) && (hi == fill_bits);
+    ok &= (ge | fl | !valid);
+    mask |= (ge && valid) ? (1u << r) : 0u;
+  }
+  mask <<= i0;
+  live = mask | (uint32_t)duo_other_i((int)mask);
+}
+
 // ---- the stages on NB slots per lane ----------------------------------------------------------------------
 template <int CH, int D, int NB, bool BIN = false>
 __device__ __forceinline__ void d_reposition(float (&q)[CH * D], unsigned flags) {
@@ -627,10 +658,11 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
   if (lane == 0) probe_buf[22] = (int32_t)wall_clock64();  // the slab is in LDS
 #endif
 
-  // ---- live rows, exactness guard (both lanes of a pair scan the whole game) --------------------------------
+  // ---- live rows, exactness guard: each lane of a pair scans its half of the game's rows, the masks meet through DPP
+  // (rounds 2-4 had both lanes scan the whole game: 1.3 us of a wave's 15.7, scripts/probe_timeline.py) -----------
   uint32_t gmask;
   bool ok;
-  scan_image<M, D>(mine, fill, gmask, ok);
+  duo_scan_half<M, D>(mine, fill, h, gmask, ok);
   if (!active) {
     gmask = 0;
     ok = true;

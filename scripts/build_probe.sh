@@ -19,9 +19,7 @@ done
 wait
 # the two-lane kernel's time-line probe (HK_DUO_PROBE: per-wave time stamps over game_length_out) at (20,3)
 /opt/rocm/bin/hipcc ${FLAGS/-DHK_QUAD_PROBE/-DHK_DUO_PROBE} -DHK_SPEC_M=20 -DHK_SPEC_D=3 -c $C/hk_duo_spec.hip -o build_probe/duo_20_3.o
-# the pool kernel's time-line probe (HK_POOL_PROBE) at (20,3)
-/opt/rocm/bin/hipcc ${FLAGS/-DHK_QUAD_PROBE/-DHK_POOL_PROBE} -DHK_SPEC_M=20 -DHK_SPEC_D=3 -c $C/hk_pool_spec.hip -o build_probe/pool_20_3.o
-OTHERS=$(ls $C/build/*.o | grep -v quad_ | grep -v duo_20_3 | grep -v pool_20_3)
-OBJS="$OBJS build_probe/duo_20_3.o build_probe/pool_20_3.o"
+OTHERS=$(ls $C/build/*.o | grep -v "/quad_" | grep -v duo_20_3)
+OBJS="$OBJS build_probe/duo_20_3.o"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OTHERS $OBJS -o build_probe/libhk_probe.so
 ls -la build_probe/libhk_probe.so
