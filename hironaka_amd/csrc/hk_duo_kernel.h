@@ -863,6 +863,9 @@ __global__ __launch_bounds__(kWave, 2) void duo_kernel(const float* in0, int64_t
         const unsigned st = (end_sort && t + 1 == nsteps) ? (stages & ~(unsigned)HK_STAGE_RESCALE) : stages;
         rescale_pending = end_sort && t + 1 == nsteps && (stages & HK_STAGE_RESCALE);
         np = d_stages<CH, D, NB, true>(q, c, axis, np, h, flags, st, mask);
+#ifdef HK_DUO_PROBE
+        if (lane == 0 && t == 0) probe_buf[20] = (int32_t)wall_clock64();  // step 0: the stages are done
+#endif
         if (!active) np = 2;
         const bool done = np < 2;
         if (done && length < 0) length = t + 1;

@@ -41,6 +41,11 @@ usp = lambda x: ((x - (base & 0xFFFFFFFF)) & 0xFFFFFFFF) / 100.0
 print("prologue (since the wave's start): window filled %.2f, slab in LDS %.2f, scanned %.2f, rows in registers %.2f; "
       "epilogue (loop done -> end) %.2f" % ((usp(pa) - us(t0)).mean(), (usp(pb) - us(t0)).mean(), (us(t1) - us(t0)).mean(),
                                               (usp(pg) - us(t0)).mean(), (us(t3) - us(t2)).mean()))
+ps = full[:, 8 + 20] & 0xFFFFFFFF
+d_stages = ((ps - pg) & 0xFFFFFFFF) / 100.0
+d_rest = ((((full[:, 8] & 0xFFFFFFFF) >> 4) - (ps & 0x0FFFFFFF)) & 0x0FFFFFFF) / 100.0
+print("step 0: rows in registers -> stages done %.2f us, stages done -> end of the step (counts, re-deal) %.2f us" % (
+    d_stages.mean(), d_rest.mean()))
 # per-step stamps (probe build): time of each step and the slots per lane after it
 st = full[:, 8:28] & 0xFFFFFFFF  # (entries 21 - 23 of the buffer hold the prologue stamps)
 clk = (st >> 4); sm = st & 15
